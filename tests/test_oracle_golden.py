@@ -1,0 +1,171 @@
+"""The oracle (oracle/*.py) against the golden vectors captured from the reference's own qdiff
+package (tests/golden/make_golden.py).  CPU only.  Integer codes: bit-exact.  fp32 params: exact
+or <= 1 ulp where torch and numpy may order a reduction differently."""
+import numpy as np
+import pytest
+
+from oracle import kernel_ref as kr
+from oracle import qdiff_ref as qr
+
+
+def ulp_close(a, b, ulps=1):
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    return np.all(np.abs(a - b) <= ulps * np.spacing(np.maximum(np.abs(a), np.abs(b))))
+
+
+@pytest.mark.parametrize("name", ["a2_dynamic_7x64", "a2_dynamic_32x1536", "a2_dynamic_5x5120"])
+def test_a2_dynamic_quantizer_bit_exact(golden, name):
+    g = golden(name)
+    q, delta = qr.dynamic_quantize_sym(g["x"], 8)
+    assert np.array_equal(delta, g["delta"])
+    assert np.array_equal(q, g["q"].astype(np.int32))
+    assert np.array_equal(qr.dynamic_fake_quant_sym(g["x"], 8), g["dequant"])
+    # eps branch really exercised: the zero row has delta == 1e-6 and q == 0
+    assert delta[0] == np.float32(1e-6) and not q[0].any()
+
+
+@pytest.mark.parametrize("name", ["a1_static_16x64", "a1_static_12x1536"])
+@pytest.mark.parametrize("tag,bits,sym", [("a8", 8, False), ("a4", 4, False), ("s8", 8, True)])
+def test_a1_static_quantizer_bit_exact(golden, name, tag, bits, sym):
+    g = golden(name)
+    delta, zp = qr.static_quant_params(g["w"], bits, sym)
+    assert np.array_equal(delta, g[f"{tag}_delta"])
+    assert np.array_equal(zp, g[f"{tag}_zp"])
+    q = qr.static_quantize(g["w"], delta, zp, bits, sym)
+    assert np.array_equal(q, g[f"{tag}_q"].astype(np.int32))
+    deq, _, _ = qr.static_fake_quant(g["w"], bits, sym)
+    assert np.array_equal(deq, g[f"{tag}_dequant"])
+    if not sym:  # asymmetric codes stay inside the b-bit signed range although the clamp is looser (D9)
+        assert q.min() >= -(2 ** (bits - 1)) and q.max() <= 2 ** (bits - 1) - 1
+        # all-positive row -> min clamps to 0 -> zp == 2**(b-1); all-negative row -> max clamps to 0
+        assert zp[0] == 2 ** (bits - 1)
+
+
+@pytest.mark.parametrize("name", ["a1_static_16x64", "a1_static_12x1536"])
+def test_a12_int8_weight_export(golden, name):
+    g = golden(name)
+    q, s16, z16 = qr.export_int8_weight(g["w"], g["a8_delta"], g["a8_zp"])
+    assert np.array_equal(s16, g["a12_scale_f16"]) and np.array_equal(z16, g["a12_zp_f16"])
+    assert np.array_equal(q, g["a12_int_weight"])
+
+
+def test_a7_mixed_precision(golden):
+    g = golden("a7_mixed_24x128")
+    d, z = qr.mixed_static_quant_params(g["w"], [4, 8])
+    assert np.array_equal(d, g["delta_list"]) and np.array_equal(z, g["zp_list"])
+    deq8, _, _ = qr.static_fake_quant(g["w"], 8, False, (d[1], z[1]))
+    deq4, _, _ = qr.static_fake_quant(g["w"], 4, False, (d[0], z[0]))
+    assert np.array_equal(deq8, g["dequant8"]) and np.array_equal(deq4, g["dequant4"])
+
+
+def test_a3_quantized_linear(golden):
+    g = golden("a3_qlinear")
+    wd, delta, zp = qr.static_fake_quant(g["w"], 8, False)
+    assert np.array_equal(wd, g["w_dequant"])
+    assert np.array_equal(delta, g["w_delta"]) and np.array_equal(zp, g["w_zp"])
+    y = qr.quantized_linear(g["x"], wd, g["b"])
+    # fp32 GEMM summation order differs between BLAS builds: tolerance, not bits
+    np.testing.assert_allclose(y, g["y"], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("n", [96, 1536, 5120, 8960])
+def test_a5_hadamard(golden, n):
+    g = golden(f"a5_hadamard_{n}")
+    _, K = qr.had_k(n)
+    assert K == int(g["K"])
+    hx = qr.matmul_hadU(g["x"])
+    np.testing.assert_allclose(hx, g["hadU_x"], rtol=0, atol=1e-12)
+    if "xR" in g:
+        R = qr.hadamard_from_signs(g["signs"])
+        assert np.abs(R @ R.T - np.eye(n)).max() < 1e-6  # fp32 sqrt(n) divisor => ~1e-8 off orthonormal
+        np.testing.assert_allclose(g["x"] @ R, g["xR"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(qr.matmul_hadU(g["x"] * g["signs"]), g["xR"], rtol=0, atol=1e-12)
+        if "R" in g:
+            assert np.array_equal(R, g["R"])
+        else:
+            assert np.array_equal(R[[0, 1, 777, n - 1]], g["R_rows"])
+
+
+def test_a5_unsupported_sizes():
+    with pytest.raises(AssertionError):  # 13824 = 144 x 96: the reference asserts too
+        qr.had_k(13824)
+
+
+def test_a4_viditq_layer(golden):
+    g = golden("a4_viditq")
+    mask = qr.vidit_channel_mask(g["w"], g["act_mask"], 0.5665)
+    assert ulp_close(mask, g["channel_mask"], 2)  # powf: libm vs torch vectorised pow
+    mask = g["channel_mask"]
+    R = qr.hadamard_from_signs(g["signs"])
+    w_first, _, _ = qr.static_fake_quant(g["w"], 8, False)
+    assert np.array_equal(w_first, g["w_first"])
+    w_final, delta, zp = qr.vidit_weight(g["w"], mask, R, 8, False)
+    assert np.array_equal(delta, g["w_delta"]) and np.array_equal(zp, g["w_zp"])
+    assert np.array_equal(w_final, g["w_final"])
+    y = qr.vidit_linear(g["x"], w_final, g["b"], mask, R)
+    np.testing.assert_allclose(y, g["y"], rtol=2e-5, atol=2e-5)
+
+
+def test_a8_calibration(golden):
+    g = golden("a8_calib")
+    stacked = np.stack([qr.calib_channel_absmax(c) for c in g["calls"]])
+    assert np.array_equal(stacked, g["stacked"])
+    am = qr.calib_act_mask(stacked)
+    assert np.array_equal(am, g["act_mask"])
+    assert am[7] == np.float32(1e-3)  # floor branch
+
+
+def test_kbench_gemm(golden):
+    g = golden("kbench_gemm")
+    acc = kr.w8a8_o32(g["a"], g["w"])
+    assert np.array_equal(acc, g["acc"])
+    y = kr.w8a8_epilogue(acc, g["sa"], g["sw"], g["bias"], g["a_sum"], g["zp"])
+    np.testing.assert_allclose(y, g["y_asym_f32"], rtol=1e-6, atol=1e-3)
+    ya = kr.w8a8_of16_bias_weight_asym(g["a"], g["w"], g["bias"], g["sa"], g["sw"], g["a_sum"], g["zp"])
+    ys = kr.w8a8_of16_bias_weight_sym(g["a"], g["w"], g["bias"], g["sa"], g["sw"])
+    # fp16 outputs of magnitude ~1e3: 1 fp16 ulp = 0.5..1
+    assert np.abs(ya.astype(np.float32) - g["y_asym"].astype(np.float32)).max() <= 1.0
+    assert np.abs(ys.astype(np.float32) - g["y_sym"].astype(np.float32)).max() <= 1.0
+
+
+def test_kbench_quant(golden):
+    g = golden("kbench_quant")
+    q, scale, s = kr.quant_sum(g["x"])
+    assert np.array_equal(scale, g["scale"])
+    assert np.array_equal(q, g["q"])
+    np.testing.assert_allclose(s.astype(np.float16).astype(np.float32), g["sum"].astype(np.float32), rtol=2e-3, atol=2e-2)
+    gq, gscale, _ = kr.gelu_quant_sum(g["x"])
+    np.testing.assert_allclose(gscale, g["gelu_scale"], rtol=1e-5)
+    d = np.abs(gq.astype(np.int32) - g["gelu_q"].astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3  # tanh implementations differ in the last ulp
+
+
+def test_kbench_layernorm(golden):
+    g = golden("kbench_layernorm")
+    T = g["x"].shape[1]
+    x = g["x"].reshape(-1, g["x"].shape[-1])
+    ln = kr.layernorm_nobias(x, g["weight"], 1e-5)
+    np.testing.assert_allclose(ln, g["ln"].reshape(ln.shape), rtol=1e-4, atol=1e-4)
+    t2i = kr.layernorm_t2i(x, g["weight"], g["shift"], g["scale_msa"], 1e-5, T)
+    np.testing.assert_allclose(t2i, g["ln_t2i"].reshape(t2i.shape), rtol=1e-4, atol=2e-4)
+    q, scale, s = kr.layernorm_t2i_quant_sum(x, g["weight"], g["shift"], g["scale_msa"], 1e-5, T)
+    np.testing.assert_allclose(scale, g["q_scale"], rtol=1e-5)
+    d = np.abs(q.astype(np.int32) - g["q"].astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3
+    np.testing.assert_allclose(s, g["q_sum"], rtol=1e-3, atol=0.2)
+
+
+def test_sim_and_kernel_modes_agree(golden):
+    """F.linear on dequantised values == int GEMM + asym epilogue."""
+    g = golden("a3_qlinear")
+    x = g["x"].reshape(-1, g["x"].shape[-1])
+    qa, da = qr.dynamic_quantize_sym(x)
+    dw, zw = qr.static_quant_params(g["w"], 8, False)
+    qw = qr.static_quantize(g["w"], dw, zw, 8, False)
+    acc = kr.w8a8_o32(qa, qw)
+    a_sum = qa.sum(axis=1).astype(np.float32) * da
+    y_k = kr.w8a8_epilogue(acc, da, dw, g["b"], a_sum, zw)
+    y_s = kr.fake_quant_linear_from_int(qa, da, qw, dw, zw, g["b"])
+    np.testing.assert_allclose(y_k, y_s, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(y_k, g["y"].reshape(y_k.shape), rtol=2e-5, atol=2e-5)
