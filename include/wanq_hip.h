@@ -1,0 +1,121 @@
+/*
+ * wanq_hip.h -- C ABI of libwanq_hip.so: the MI355X (gfx950) hot path of the quantized Wan2.1 DiT.
+ *
+ * This is the drop-in boundary.  The reference has no C ABI: its "ABI" is two pybind11 modules
+ * taking torch::Tensor (ViDiT-Q/kernels/csrc/{fused,qgemm}/pybind.cpp).  Every entry point below
+ * names the reference function(s) it replaces; the Python package
+ * wan2.1-quantization_amd/viditq_extension re-exports them under the reference's own names and
+ * argument order through ctypes.
+ *
+ * Conventions
+ *   - plain device pointers + sizes, no torch types; `stream` is a hipStream_t passed as void*
+ *     (NULL = the legacy default stream).  Calls only enqueue work; nothing synchronises.
+ *   - return value 0 = enqueued; non-zero = refused (WANQ_E_*), nothing enqueued, message from
+ *     wanq_last_error().  Shape/dtype errors are reported, never asserted (the reference aborts the
+ *     process on tile-divisibility violations: w8a8_gemm_cuda.cu:678-680).
+ *   - row-major contiguous tensors; activations [rows, cols], weights [N, K] (nn.Linear layout).
+ *   - dtype codes WANQ_F16/BF16/F32 for floating tensors; per-token / per-channel vectors
+ *     (scale, sum, bias ...) carry their own dtype code so both the reference's fp16 buffers
+ *     (K/viditq_extension/nn/base.py:12-26) and fp32 buffers (simulation-path accuracy) work.
+ *   - integer results (int8 codes, int32 accumulators) are bit-exact w.r.t. oracle/; see DESIGN.md.
+ */
+#ifndef WANQ_HIP_H
+#define WANQ_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { WANQ_F16 = 0, WANQ_BF16 = 1, WANQ_F32 = 2, WANQ_I32 = 3, WANQ_I16 = 4 };
+
+enum {
+  WANQ_OK = 0,
+  WANQ_E_ARG = 1,     /* bad pointer / dtype / flag combination */
+  WANQ_E_SHAPE = 2,   /* unsupported shape (message says which rule) */
+  WANQ_E_LAUNCH = 3   /* hipGetLastError() after launch was not hipSuccess */
+};
+
+/* Last refusal message of the calling thread ("" if none).  Never NULL. */
+const char* wanq_last_error(void);
+/* Version of this ABI (bumped on any signature change). */
+int wanq_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-token dynamic int8 quantisation (+ dequantised row sum).
+ *   q[r,c]   = clamp(rne(x[r,c] / scale_r), -128, 127),  scale_r = max(absmax_r / 127, 1e-6)
+ *   sum[r]   = scale_r * sum_c q[r,c]                       (sum may be NULL)
+ * act: 0 = identity, 1 = tanh-GELU applied to x first.
+ * static_amax != 0: `scale` is an INPUT holding absmax_r (reference quant_sum_static reads it so).
+ * Replaces fused.quant_sum / quant_sum_static / gelu_quant_sum
+ *   (ViDiT-Q/kernels/csrc/fused/fused.cu:30-232, hosts :524-706) and is bit-identical to
+ *   DynamicQuantizer.quantize (quant_utils/qdiff/base/base_quantizer.py:101-157) for any cols % 8 == 0
+ *   (the reference needs cols % 128 == 0 and cols <= 8192). */
+int wanq_quant_rows(const void* x, int x_dtype, int8_t* q, void* scale, void* sum, int vec_dtype,
+                    int64_t rows, int cols, int act, int static_amax, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm (no bias, optional gamma) -> optional adaLN modulate -> fp output OR int8 quant (+sum).
+ *   y = (x - mean) * rstd * gamma;  y = y * (1 + mscale[b]) + mshift[b]   (b = row / rows_per_batch)
+ *   out_fp != NULL : write y in out_dtype.      q != NULL : quantise y like wanq_quant_rows.
+ * gamma / mshift / mscale may be NULL (identity).  mod_stride = elements between batches.
+ * Statistics and modulation are fp32 (simulation-path semantics, Wan model.py:327), not half2.
+ * Replaces fused.layernorm_nobias, layernorm_nobias_quant_nosum_fuse, layernorm_nobias_quant_sum_fuse,
+ *   layernorm_nobias_t2i_fuse, layernorm_nobias_t2i_quant_sum_fuse
+ *   (ViDiT-Q/kernels/csrc/fused/fused.cu:234-380, hosts :485-522,:708-915).  Any cols % 8 == 0 up to
+ *   16384 (the reference: cols/4 <= 1024 threads). */
+int wanq_layernorm_rows(const void* x, int x_dtype, const void* gamma, const void* mshift,
+                        const void* mscale, int mod_dtype, int64_t mod_stride, int64_t rows_per_batch,
+                        float eps, void* out_fp, int out_dtype, int8_t* q, void* scale, void* sum,
+                        int vec_dtype, int64_t rows, int cols, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * out = y * gate[b] + residual   (fp32 arithmetic; each tensor has its own dtype).
+ * Replaces fused.gate_residual_fuse (fused.cu:382-483, host :917-961). */
+int wanq_gate_residual(const void* y, int y_dtype, const void* gate, int gate_dtype, int64_t gate_stride,
+                       const void* residual, int res_dtype, void* out, int out_dtype, int64_t rows,
+                       int cols, int64_t rows_per_batch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * W8A8 GEMM on int8 MFMA with fused dequant epilogue:
+ *   acc[m,n] = sum_k a[m,k] * w[n,k]                                  (int32, exact)
+ *   y        = acc*sa[m]*sw[n] (+ asum[m]*zp[n]*sw[n]) (+ bias[n])     (fp32, this order)
+ *   y        = gelu_tanh(y)                     if WANQ_EPI_GELU
+ *   y        = residual[m,n] + y * gate[n]      if WANQ_EPI_GATE_RES  (gate fp32[N], residual/out same dtype)
+ *   out      = cast(y)  to out_dtype;  out_dtype == WANQ_I32 stores acc (no scales read).
+ * sa/asum: per-token, dtype tok_dtype (F16|F32).  sw/bias: per-channel, dtype ch_dtype (F16|F32).
+ * zp: zp_dtype WANQ_I16 (reference buffer) or WANQ_F32; NULL = symmetric weights.  bias may be NULL.
+ * Any M >= 1 (ragged last tile handled in-kernel, no host padding: replaces pad_to_multiple_2d,
+ * wan/quant_wanx_cuda.py:313-328); N % 8 == 0; K % 16 == 0.
+ * Replaces qgemm.w8a8_of16_bias_weight_asym / _sym / w8a8_o32 / w8a8_of16_nobias_weight_sym_qserve
+ *   (ViDiT-Q/kernels/csrc/qgemm/w8a8/w8a8_gemm_cuda.cu:624-838, ..._qserve.cu:527-611). */
+enum { WANQ_EPI_GELU = 1, WANQ_EPI_GATE_RES = 2 };
+int wanq_gemm_w8a8(const int8_t* a, const int8_t* w, void* out, int out_dtype, const void* sa,
+                   const void* asum, int tok_dtype, const void* sw, const void* bias, int ch_dtype,
+                   const void* zp, int zp_dtype, const float* gate, const void* residual, int epi_flags,
+                   int64_t M, int N, int K, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * PTQ calibration reduction: running per-channel absmax over tokens,
+ *   colmax[c] = max(colmax[c], max_r |x[r,c]|)        (colmax fp32[cols], caller zero-initialises)
+ * Replaces SaveActivationHook.__call__ default branch
+ *   (ViDiT-Q/examples/Wan2.1/get_calib_data_wanx.py:262-267) -- and, because ptq takes .max(dim=0)
+ *   over the stacked calls (ptq_wanx.py:336), the stack itself. */
+int wanq_col_absmax(const void* x, int x_dtype, float* colmax, int64_t rows, int cols, void* stream);
+
+/* Per-row min / max / absmax of a weight matrix (StaticQuantizer.init_quant_params statistics,
+ *   quant_utils/qdiff/base/base_quantizer.py:70-90).  Any of the outputs may be NULL. */
+int wanq_row_minmax(const void* w, int w_dtype, float* row_min, float* row_max, float* row_absmax,
+                    int64_t rows, int cols, void* stream);
+
+/* Static per-output-channel weight quantisation with given params (fp32 [rows]):
+ *   q = clamp(rne(w/delta) - zp, qmin, qmax)  -> int8 codes, and/or fake-quant (q+zp)*delta -> fp32.
+ *   (base_quantizer.py:56-68; export: wan/quant_wanx_cuda.py:39-53).  q8 / deq may be NULL. */
+int wanq_weight_quant(const void* w, int w_dtype, const float* delta, const float* zp, int qmin, int qmax,
+                      int8_t* q8, float* deq, int64_t rows, int cols, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WANQ_HIP_H */

@@ -1,0 +1,93 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every symbol the header
+declares, refuses bad arguments with a message instead of crashing, and the Python mirror of the
+reference's extension modules exposes the reference's names."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "wanq_hip.h")
+LIB = os.path.join(ROOT, "wan2.1-quantization_amd", "lib", "libwanq_hip.so")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(wanq_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        import importlib.util
+
+        spec = importlib.util.spec_from_file_location("wanq_build", os.path.join(ROOT, "wan2.1-quantization_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build(verbose=False)
+    return ctypes.CDLL(LIB)
+
+
+def test_header_symbols_exported(lib):
+    syms = declared_symbols()
+    assert len(syms) >= 9
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/wanq_hip.h but not exported"
+
+
+def test_binding_covers_header(lib):
+    from viditq_extension import _C
+
+    assert set(_C.PROTOTYPES) | {"wanq_last_error", "wanq_abi_version"} == set(declared_symbols())
+
+
+def test_bad_arguments_are_refused_with_message(lib):
+    lib.wanq_last_error.restype = ctypes.c_char_p
+    rc = lib.wanq_quant_rows(None, 0, None, None, None, 0, ctypes.c_int64(4), 64, 0, 0, None)
+    assert rc == 1 and b"non-NULL" in lib.wanq_last_error()
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    rc = lib.wanq_quant_rows(p, 0, p, p, None, 0, ctypes.c_int64(4), 60, 0, 0, None)  # cols % 8 != 0
+    assert rc == 2 and b"multiple of 8" in lib.wanq_last_error()
+    rc = lib.wanq_gemm_w8a8(p, p, p, 0, p, None, 0, p, None, 0, None, 0, None, None, 0, ctypes.c_int64(8), 12, 64, None)
+    assert rc == 2 and b"N=12" in lib.wanq_last_error()
+    rc = lib.wanq_gemm_w8a8(p, p, p, 0, p, None, 0, p, None, 0, None, 0, None, None, 0, ctypes.c_int64(8), 16, 24, None)
+    assert rc == 2 and b"K=24" in lib.wanq_last_error()
+
+
+def test_reference_module_surface():
+    import viditq_extension.fused as fused
+    import viditq_extension.qgemm as qgemm
+    from viditq_extension.nn.base import QuantParams  # noqa: F401
+    from viditq_extension.nn.layernorm import LayerNormGeneral  # noqa: F401
+    from viditq_extension.nn.qlinear import W8A8OF16LinearDynamicInputScale  # noqa: F401
+
+    # K/csrc/fused/pybind.cpp:57-99 and K/csrc/qgemm/pybind.cpp:5-12
+    for n in ["quant_sum", "quant_sum_static", "gelu_quant_sum", "layernorm_nobias", "layernorm_nobias_quant_nosum_fuse",
+              "layernorm_nobias_quant_sum_fuse", "layernorm_nobias_t2i_fuse", "layernorm_nobias_t2i_quant_sum_fuse",
+              "gate_residual_fuse"]:
+        assert callable(getattr(fused, n))
+    for n in ["w8a8_of16_bias_weight_asym", "w8a8_of16_bias_weight_sym", "w8a8_o32", "w8a8_of16_nobias_weight_sym_qserve"]:
+        assert callable(getattr(qgemm, n))
+
+
+def test_no_cpu_fallback():
+    import viditq_extension.fused as fused
+    import viditq_extension.qgemm as qgemm
+
+    with pytest.raises(RuntimeError, match="must be on the GPU"):
+        fused.quant_sum(torch.zeros(4, 64, dtype=torch.float16), torch.zeros(4, dtype=torch.float16), torch.zeros(4, dtype=torch.float16))
+    with pytest.raises(RuntimeError, match="must be on the GPU"):
+        qgemm.w8a8_o32(torch.zeros(4, 64, dtype=torch.int8), torch.zeros(8, 64, dtype=torch.int8))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "wan2.1-quantization_amd")
+    for d, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(d, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"

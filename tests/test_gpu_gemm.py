@@ -1,0 +1,133 @@
+"""GPU parity of the int8-MFMA GEMM (C ABI wanq_gemm_w8a8) vs the oracle: int32 accumulators bit-exact,
+fp epilogue within one ulp of the output dtype."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kernel_ref as kr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def qgemm():
+    import viditq_extension.qgemm as m
+
+    return m
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 8, 16), (7, 24, 48), (128, 128, 128), (130, 136, 144), (257, 384, 1536),
+                                   (1000, 1536, 1536), (333, 8960, 1536), (300, 1536, 8960), (512, 5120, 5120)])
+def test_w8a8_o32_bit_exact(M, N, K):
+    rng = np.random.default_rng(M * 7 + N + K)
+    a = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+    w = rng.integers(-128, 128, size=(N, K), dtype=np.int8)
+    out = qgemm().w8a8_o32(t(a), t(w)).cpu().numpy()
+    assert np.array_equal(out, kr.w8a8_o32(a, w))
+
+
+def test_w8a8_o32_extreme_values_no_overflow():
+    """K = 13824 of -128 * -128: 2.26e8 < 2^31, the largest accumulator the 14B model can produce."""
+    M, N, K = 40, 16, 13824
+    a = np.full((M, K), -128, np.int8)
+    w = np.full((N, K), -128, np.int8)
+    w[1] = 127
+    out = qgemm().w8a8_o32(t(a), t(w)).cpu().numpy()
+    assert np.array_equal(out, kr.w8a8_o32(a, w))
+
+
+def test_identity_and_asymmetric_operand_layout():
+    """A = I check with an asymmetric weight catches a transposed C write or swapped operand roles."""
+    n = 128
+    a = np.eye(n, dtype=np.int8)
+    w = (np.arange(n)[:, None] * 3 + np.arange(n)[None, :] * 5) % 200 - 100
+    w = w.astype(np.int8)
+    out = qgemm().w8a8_o32(t(a), t(w)).cpu().numpy()
+    assert np.array_equal(out, w.T.astype(np.int32))
+
+
+def test_kbench_gemm_golden(golden):
+    """K/bench/bench_gemm.py:27-29 ground truth, reference buffer dtypes (fp16 scales, int16 zp)."""
+    g = golden("kbench_gemm")
+    args = [t(g[k]) for k in ("a", "w", "bias", "sa", "sw", "a_sum", "zp")]
+    y = qgemm().w8a8_of16_bias_weight_asym(*args)
+    assert y.dtype == torch.float16 and tuple(y.shape) == g["y_asym"].shape
+    d = np.abs(y.float().cpu().numpy() - g["y_asym_f32"])
+    assert (d <= np.maximum(np.abs(g["y_asym_f32"]) * 2 ** -10, 1e-3)).all()  # within fp16 rounding of the fp32 truth
+    ys = qgemm().w8a8_of16_bias_weight_sym(t(g["a"]), t(g["w"]), t(g["bias"]), t(g["sa"]), t(g["sw"]))
+    assert np.abs(ys.float().cpu().numpy() - g["y_sym"].astype(np.float32)).max() <= 1.0
+    yq = qgemm().w8a8_of16_nobias_weight_sym_qserve(t(g["a"]), t(g["w"]), t(g["sa"]), t(g["sw"]))
+    ref = kr.w8a8_epilogue(g["acc"], g["sa"], g["sw"])
+    np.testing.assert_allclose(yq.float().cpu().numpy(), ref, rtol=1e-3, atol=1e-2)
+    assert np.array_equal(qgemm().w8a8_o32(t(g["a"]), t(g["w"])).cpu().numpy(), g["acc"])
+
+
+@pytest.mark.parametrize("out_dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K", [(200, 136, 192), (4680, 1536, 1536)])
+def test_epilogue_variants_fp32_vectors(out_dtype, M, N, K):
+    rng = np.random.default_rng(5)
+    a = rng.integers(-127, 128, size=(M, K), dtype=np.int8)
+    w = rng.integers(-128, 128, size=(N, K), dtype=np.int8)
+    sa = rng.uniform(0.005, 0.02, M).astype(np.float32)
+    sw = rng.uniform(0.001, 0.003, N).astype(np.float32)
+    zp = rng.integers(-20, 20, N).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    asum = (a.sum(1) * sa).astype(np.float32)
+    gate = rng.normal(size=N).astype(np.float32)
+    res = rng.normal(size=(M, N)).astype(np.float32)
+    eps = {torch.float16: 2 ** -10, torch.bfloat16: 2 ** -7, torch.float32: 2e-6}[out_dtype]
+    acc = kr.w8a8_o32(a, w)
+
+    def close(y, ref):
+        y = y.float().cpu().numpy()
+        assert (np.abs(y - ref) <= np.abs(ref) * eps + 1e-4).all()
+
+    base = kr.w8a8_epilogue(acc, sa, sw, bias, asum, zp)
+    y = qgemm().w8a8_linear(t(a), t(w), t(sa), t(sw), t(bias), t(asum), t(zp), out_dtype=out_dtype)
+    close(y, base)
+    y = qgemm().w8a8_linear(t(a), t(w), t(sa), t(sw), t(bias), t(asum), t(zp), out_dtype=out_dtype, gelu=True)
+    close(y, kr.gelu_tanh(base))
+    res_t = t(res).to(out_dtype)
+    y = qgemm().w8a8_linear(t(a), t(w), t(sa), t(sw), t(bias), t(asum), t(zp), out_dtype=out_dtype, gate=t(gate), residual=res_t)
+    close(y, res_t.float().cpu().numpy() + base * gate[None, :])
+    # in-place residual update (out aliases residual), as the block uses it
+    buf = res_t.clone()
+    qgemm().w8a8_linear(t(a), t(w), t(sa), t(sw), t(bias), t(asum), t(zp), out_dtype=out_dtype, gate=t(gate), residual=buf, out=buf)
+    assert torch.equal(buf, y)
+
+
+def test_qlinear_module_from_linear_and_forward():
+    """W8A8OF16LinearDynamicInputScale.from_linear + forward == fake-quant linear on the same codes."""
+    from viditq_extension.nn import LayerNormGeneral, QuantParams, W8A8OF16LinearDynamicInputScale  # noqa: F401
+    import viditq_extension.fused as fused
+
+    g = torch.Generator().manual_seed(0)
+    lin = torch.nn.Linear(1536, 384)
+    lin.weight.data = torch.randn(384, 1536, generator=g) * 0.05
+    lin = lin.half().to(DEV)
+    ql = W8A8OF16LinearDynamicInputScale.from_linear(lin, weight_sym=False)
+    x = torch.randn(2, 77, 1536, generator=g).half().to(DEV)
+    qp = QuantParams(2 * 77, has_sum_input=True, device=DEV)
+    xq = fused.quant_sum(x, qp.sum_input, qp.scale_input)
+    y = ql(xq, qp)
+    assert y.shape == (2, 77, 384) and y.dtype == torch.float16
+    ref = kr.fake_quant_linear_from_int(xq.cpu().numpy().reshape(-1, 1536).astype(np.int32), qp.scale_input.float().cpu().numpy(),
+                                        ql.weight.cpu().numpy().astype(np.int32), ql.scale_weight.float().cpu().numpy(),
+                                        ql.zp_weight.float().cpu().numpy(), ql.bias.float().cpu().numpy())
+    np.testing.assert_allclose(y.float().cpu().numpy().reshape(-1, 384), ref, rtol=5e-3, atol=5e-3)
+    # and close to the fp16 linear itself (quantisation error only)
+    yfp = torch.nn.functional.linear(x, lin.weight, lin.bias)
+    assert (y - yfp).abs().max().item() < 0.05 * yfp.abs().max().item()
+
+
+def test_shape_errors_raise_runtime_error():
+    a = torch.zeros(8, 24, dtype=torch.int8, device=DEV)
+    w = torch.zeros(16, 24, dtype=torch.int8, device=DEV)
+    with pytest.raises(RuntimeError, match="K=24"):
+        qgemm().w8a8_o32(a, w)
+    with pytest.raises(RuntimeError, match="shape"):
+        qgemm().w8a8_o32(torch.zeros(8, 32, dtype=torch.int8, device=DEV), w)

@@ -1,0 +1,470 @@
+// Row-wise HBM-bound kernels: per-token int8 quantisation, LayerNorm+modulate(+quant), gate-residual,
+// calibration absmax, weight row statistics and static weight quantisation.
+//
+// Data layout: every tensor is row-major [rows, cols]; a row is split into 16-byte-aligned chunks of
+// 8 elements; chunk c of a row goes to lane (c % (64*WPR)), so one wave instruction reads
+// 64 consecutive chunks (1 KiB for 16-bit inputs, 2 KiB for fp32) -- fully coalesced.
+// A row lives in registers between its reductions and its store: each element is read from HBM once
+// and written once (algorithmic bytes == traffic).
+//   WPR = 1: one wave per row (cols <= 2048), 4 rows per 256-thread workgroup, no barriers, no LDS.
+//   WPR = 4: four waves per row (cols <= 16384), reductions finished through 64 B of LDS.
+#include "wanq_common.h"
+
+namespace wanq {
+
+struct RowParams {
+  const void* x;
+  int x_dtype;
+  // layernorm
+  const void* gamma;
+  const void* mshift;
+  const void* mscale;
+  int mod_dtype;
+  int64_t mod_stride;
+  int64_t rows_per_batch;
+  float eps;
+  // outputs
+  void* out_fp;
+  int out_dtype;
+  int8_t* q;
+  void* scale;
+  void* sum;
+  int vec_dtype;
+  int64_t rows;
+  int cols;
+  int act;
+  int static_amax;
+};
+
+__device__ __forceinline__ void load8_rt(const void* base, int dt, int64_t elem, float (&v)[8]) {
+  if (dt == WANQ_F16) Io<F16>::load8(base, elem, v);
+  else if (dt == WANQ_BF16) Io<BF16>::load8(base, elem, v);
+  else Io<F32>::load8(base, elem, v);
+}
+__device__ __forceinline__ void store8_rt(void* base, int dt, int64_t elem, const float (&v)[8]) {
+  if (dt == WANQ_F16) Io<F16>::store8(base, elem, v);
+  else if (dt == WANQ_BF16) Io<BF16>::store8(base, elem, v);
+  else Io<F32>::store8(base, elem, v);
+}
+
+template <int WPR>
+struct RowReduce {
+  // LDS slots: one float per wave per reduction id; every reduction id is used once per kernel, so a
+  // single barrier per reduction suffices.
+  float* slots;
+  int wave;
+  __device__ __forceinline__ float sum(float v, int id) {
+    v = wave_sum(v);
+    if (WPR == 1) return v;
+    if ((threadIdx.x & 63) == 0) slots[id * WPR + wave] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPR; ++w) t += slots[id * WPR + w];
+    return t;
+  }
+  __device__ __forceinline__ float max(float v, int id) {
+    v = wave_max(v);
+    if (WPR == 1) return v;
+    if ((threadIdx.x & 63) == 0) slots[id * WPR + wave] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPR; ++w) t = fmaxf(t, slots[id * WPR + w]);
+    return t;
+  }
+  __device__ __forceinline__ int isum(int v, int id) {
+    v = wave_sum(v);
+    if (WPR == 1) return v;
+    if ((threadIdx.x & 63) == 0) reinterpret_cast<int*>(slots)[id * WPR + wave] = v;
+    __syncthreads();
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < WPR; ++w) t += reinterpret_cast<int*>(slots)[id * WPR + w];
+    return t;
+  }
+};
+
+template <int WPR, int NCH, bool LN>
+__global__ __launch_bounds__(256) void rowwise_kernel(const RowParams p) {
+  __shared__ float red_slots[4 * 4];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t row = (WPR == 1) ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
+  if (WPR == 1 && row >= p.rows) return;  // whole wave leaves; no barriers on this path
+  RowReduce<WPR> red{red_slots, wave};
+  const int sub = (WPR == 1) ? 0 : wave;
+  const int C = p.cols;
+  const int64_t rbase = row * (int64_t)C;
+
+  float v[NCH][8];
+  bool ok[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c0 = (sub * 64 + lane + i * 64 * WPR) * 8;
+    ok[i] = c0 < C;
+    if (ok[i]) {
+      load8_rt(p.x, p.x_dtype, rbase + c0, v[i]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    }
+  }
+
+  if (LN) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[i][j];
+    const float mean = red.sum(s, 0) / (float)C;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (ok[i]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = v[i][j] - mean;
+          s2 += d * d;
+        }
+      }
+    const float var = red.sum(s2, 1) / (float)C;
+    const float rstd = 1.0f / sqrtf(var + p.eps);
+    const int64_t mb = (row / p.rows_per_batch) * p.mod_stride;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (ok[i]) {
+        const int c0 = (sub * 64 + lane + i * 64 * WPR) * 8;
+        float g[8], sh[8], sc[8];
+        if (p.gamma) load8_rt(p.gamma, p.mod_dtype, c0, g);
+        if (p.mscale) load8_rt(p.mscale, p.mod_dtype, mb + c0, sc);
+        if (p.mshift) load8_rt(p.mshift, p.mod_dtype, mb + c0, sh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float y = (v[i][j] - mean) * rstd;
+          if (p.gamma) y *= g[j];
+          if (p.mscale) y *= (1.0f + sc[j]);
+          if (p.mshift) y += sh[j];
+          v[i][j] = y;
+        }
+      }
+  } else if (p.act == 1) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = gelu_tanh_f32(v[i][j]);
+  }
+
+  if (p.out_fp) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (ok[i]) store8_rt(p.out_fp, p.out_dtype, rbase + (sub * 64 + lane + i * 64 * WPR) * 8, v[i]);
+  }
+  if (!p.q) return;
+
+  float amax;
+  if (p.static_amax) {
+    amax = vec_load(p.scale, p.vec_dtype, row);
+  } else {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[i][j]));
+    amax = red.max(m, 2);
+  }
+  float scale = amax / 127.0f;
+  if (scale < 1e-6f) scale = 1e-6f;  // qdiff eps rule (base_quantizer.py:122-127)
+  const float inv = 1.0f / scale;
+  int isum = 0;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    int qi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      qi[j] = quant_div_rne(v[i][j], scale, inv);
+      isum += qi[j];
+    }
+    if (ok[i]) {
+      const uint2 pk = make_uint2(pack4_i8(qi[0], qi[1], qi[2], qi[3]), pack4_i8(qi[4], qi[5], qi[6], qi[7]));
+      *reinterpret_cast<uint2*>(p.q + rbase + (sub * 64 + lane + i * 64 * WPR) * 8) = pk;
+    }
+  }
+  if (p.sum) {
+    const int tot = red.isum(isum, 3);
+    if (lane == 0 && sub == 0) vec_store(p.sum, p.vec_dtype, row, (float)tot * scale);
+  }
+  if (!p.static_amax && lane == 0 && sub == 0) vec_store(p.scale, p.vec_dtype, row, scale);
+}
+
+template <bool LN>
+static int launch_rowwise(const RowParams& p, hipStream_t st, const char* what) {
+  const int chunks = p.cols / 8;
+  const int64_t rows = p.rows;
+#define WANQ_RW(WPR, NCH)                                                                       \
+  hipLaunchKernelGGL((rowwise_kernel<WPR, NCH, LN>), dim3((unsigned)((WPR) == 1 ? (rows + 3) / 4 : rows)), \
+                     dim3(256), 0, st, p)
+  if (chunks <= 64) WANQ_RW(1, 1);
+  else if (chunks <= 128) WANQ_RW(1, 2);
+  else if (chunks <= 192) WANQ_RW(1, 3);
+  else if (chunks <= 256) WANQ_RW(1, 4);
+  else if (chunks <= 512) WANQ_RW(4, 2);
+  else if (chunks <= 768) WANQ_RW(4, 3);
+  else if (chunks <= 1024) WANQ_RW(4, 4);
+  else if (chunks <= 1280) WANQ_RW(4, 5);
+  else if (chunks <= 1536) WANQ_RW(4, 6);
+  else if (chunks <= 1792) WANQ_RW(4, 7);
+  else WANQ_RW(4, 8);
+#undef WANQ_RW
+  return check_launch(what);
+}
+
+static int check_rows_cols(const char* what, int64_t rows, int cols) {
+  WANQ_REQUIRE(rows >= 0 && rows < (1ll << 31), WANQ_E_SHAPE, "%s: rows=%lld out of range", what, (long long)rows);
+  WANQ_REQUIRE(cols >= 8 && cols % 8 == 0 && cols <= 16384, WANQ_E_SHAPE,
+               "%s: cols=%d must be a multiple of 8 in [8, 16384]", what, cols);
+  return WANQ_OK;
+}
+
+// ------------------------------------------------------------------------------ gate * y + residual
+struct GateParams {
+  const void* y;
+  const void* gate;
+  const void* res;
+  void* out;
+  int y_dtype, gate_dtype, res_dtype, out_dtype;
+  int64_t gate_stride, rows_per_batch, rows;
+  int cols;
+};
+
+__global__ __launch_bounds__(256) void gate_residual_kernel(const GateParams p) {
+  const int cpr = p.cols / 8;  // chunks per row
+  const int64_t total = p.rows * (int64_t)cpr;
+  for (int64_t ch = (int64_t)blockIdx.x * 256 + threadIdx.x; ch < total; ch += (int64_t)gridDim.x * 256) {
+    const int64_t row = ch / cpr;
+    const int c0 = (int)(ch - row * cpr) * 8;
+    float y[8], g[8], r[8];
+    load8_rt(p.y, p.y_dtype, row * p.cols + c0, y);
+    load8_rt(p.gate, p.gate_dtype, (row / p.rows_per_batch) * p.gate_stride + c0, g);
+    load8_rt(p.res, p.res_dtype, row * p.cols + c0, r);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[j] = y[j] * g[j] + r[j];
+    store8_rt(p.out, p.out_dtype, row * p.cols + c0, y);
+  }
+}
+
+// ------------------------------------------------------------------------------ calibration: column absmax
+// Each workgroup owns a 512-column panel (64 lanes x 8 columns) and a slab of rows; a lane keeps 8
+// running maxima in registers, the 4 waves of a workgroup take rows round-robin, partials meet in LDS
+// and one atomicMax per column per workgroup goes to HBM (non-negative floats order like uints).
+template <typename T>
+__global__ __launch_bounds__(256) void col_absmax_kernel(const void* x, float* colmax, int64_t rows, int cols,
+                                                         int rows_per_block) {
+  __shared__ float part[4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 512 + lane * 8;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
+  float m[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) m[j] = 0.f;
+  if (c0 < cols) {
+    int64_t r = r0 + wave;
+    for (; r + 12 < r1; r += 16) {  // 4 independent loads in flight per lane
+      float a[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) Io<T>::load8(x, (r + 4 * u) * cols + c0, a[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], fabsf(a[u][j]));
+    }
+    for (; r < r1; r += 4) {
+      float a[8];
+      Io<T>::load8(x, r * cols + c0, a);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], fabsf(a[j]));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[wave][lane * 8 + j] = m[j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < 512; c += 256) {
+    const int col = blockIdx.x * 512 + c;
+    if (col < cols) {
+      const float v = fmaxf(fmaxf(part[0][c], part[1][c]), fmaxf(part[2][c], part[3][c]));
+      atomicMax(reinterpret_cast<unsigned int*>(colmax + col), __float_as_uint(v));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ weight row statistics
+template <int WPR, int NCH>
+__global__ __launch_bounds__(256) void row_minmax_kernel(const void* w, int dt, float* rmin, float* rmax,
+                                                         float* rabs, int64_t rows, int cols) {
+  __shared__ float slots[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (WPR == 1) ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
+  if (WPR == 1 && row >= rows) return;
+  const int sub = (WPR == 1) ? 0 : wave;
+  float lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c0 = (sub * 64 + lane + i * 64 * WPR) * 8;
+    if (c0 < cols) {
+      float v[8];
+      load8_rt(w, dt, row * cols + c0, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        lo = fminf(lo, v[j]);
+        hi = fmaxf(hi, v[j]);
+      }
+    }
+  }
+  lo = wave_min(lo);
+  hi = wave_max(hi);
+  if (WPR > 1) {
+    if (lane == 0) {
+      slots[0][wave] = lo;
+      slots[1][wave] = hi;
+    }
+    __syncthreads();
+    lo = fminf(fminf(slots[0][0], slots[0][1]), fminf(slots[0][2], slots[0][3]));
+    hi = fmaxf(fmaxf(slots[1][0], slots[1][1]), fmaxf(slots[1][2], slots[1][3]));
+  }
+  if (lane == 0 && sub == 0) {
+    if (rmin) rmin[row] = lo;
+    if (rmax) rmax[row] = hi;
+    if (rabs) rabs[row] = fmaxf(fabsf(lo), fabsf(hi));
+  }
+}
+
+// ------------------------------------------------------------------------------ static weight quantisation
+__global__ __launch_bounds__(256) void weight_quant_kernel(const void* w, int dt, const float* delta, const float* zp,
+                                                           int qmin, int qmax, int8_t* q8, float* deq, int64_t rows,
+                                                           int cols) {
+  const int cpr = cols / 8;
+  const int64_t total = rows * (int64_t)cpr;
+  for (int64_t ch = (int64_t)blockIdx.x * 256 + threadIdx.x; ch < total; ch += (int64_t)gridDim.x * 256) {
+    const int64_t row = ch / cpr;
+    const int c0 = (int)(ch - row * cpr) * 8;
+    float v[8];
+    load8_rt(w, dt, row * cols + c0, v);
+    const float d = delta[row], z = zp[row];
+    int qi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      // rne(w/delta) - zp, clamp   (base_quantizer.py:64-67); true division: runs once per model
+      float t = rintf(v[j] / d) - z;
+      t = fminf(fmaxf(t, (float)qmin), (float)qmax);
+      qi[j] = (int)t;
+      v[j] = (t + z) * d;
+    }
+    if (q8)
+      *reinterpret_cast<uint2*>(q8 + row * cols + c0) =
+          make_uint2(pack4_i8(qi[0], qi[1], qi[2], qi[3]), pack4_i8(qi[4], qi[5], qi[6], qi[7]));
+    if (deq) Io<F32>::store8(deq, row * cols + c0, v);
+  }
+}
+
+}  // namespace wanq
+
+using namespace wanq;
+
+extern "C" int wanq_quant_rows(const void* x, int x_dtype, int8_t* q, void* scale, void* sum, int vec_dtype,
+                               int64_t rows, int cols, int act, int static_amax, void* stream) {
+  WANQ_REQUIRE(x && q && scale, WANQ_E_ARG, "wanq_quant_rows: x, q and scale must be non-NULL");
+  WANQ_REQUIRE(is_fp(x_dtype) && is_vec(vec_dtype), WANQ_E_ARG, "wanq_quant_rows: bad dtype code (x=%d vec=%d)", x_dtype, vec_dtype);
+  WANQ_REQUIRE(act == 0 || act == 1, WANQ_E_ARG, "wanq_quant_rows: act must be 0 or 1");
+  if (int e = check_rows_cols("wanq_quant_rows", rows, cols)) return e;
+  if (rows == 0) return WANQ_OK;
+  RowParams p{};
+  p.x = x; p.x_dtype = x_dtype; p.q = q; p.scale = scale; p.sum = sum; p.vec_dtype = vec_dtype;
+  p.rows = rows; p.cols = cols; p.act = act; p.static_amax = static_amax; p.rows_per_batch = 1;
+  return launch_rowwise<false>(p, (hipStream_t)stream, "wanq_quant_rows");
+}
+
+extern "C" int wanq_layernorm_rows(const void* x, int x_dtype, const void* gamma, const void* mshift,
+                                   const void* mscale, int mod_dtype, int64_t mod_stride, int64_t rows_per_batch,
+                                   float eps, void* out_fp, int out_dtype, int8_t* q, void* scale, void* sum,
+                                   int vec_dtype, int64_t rows, int cols, void* stream) {
+  WANQ_REQUIRE(x && (out_fp || q), WANQ_E_ARG, "wanq_layernorm_rows: need x and at least one of out_fp / q");
+  WANQ_REQUIRE(is_fp(x_dtype), WANQ_E_ARG, "wanq_layernorm_rows: bad x dtype %d", x_dtype);
+  WANQ_REQUIRE(!(gamma || mshift || mscale) || is_fp(mod_dtype), WANQ_E_ARG, "wanq_layernorm_rows: bad mod dtype %d", mod_dtype);
+  WANQ_REQUIRE(!out_fp || is_fp(out_dtype), WANQ_E_ARG, "wanq_layernorm_rows: bad out dtype %d", out_dtype);
+  WANQ_REQUIRE(!q || (scale && is_vec(vec_dtype)), WANQ_E_ARG, "wanq_layernorm_rows: q needs scale and a valid vec dtype");
+  WANQ_REQUIRE(rows_per_batch >= 1, WANQ_E_ARG, "wanq_layernorm_rows: rows_per_batch must be >= 1");
+  if (int e = check_rows_cols("wanq_layernorm_rows", rows, cols)) return e;
+  if (rows == 0) return WANQ_OK;
+  RowParams p{};
+  p.x = x; p.x_dtype = x_dtype; p.gamma = gamma; p.mshift = mshift; p.mscale = mscale; p.mod_dtype = mod_dtype;
+  p.mod_stride = mod_stride; p.rows_per_batch = rows_per_batch; p.eps = eps; p.out_fp = out_fp; p.out_dtype = out_dtype;
+  p.q = q; p.scale = scale; p.sum = sum; p.vec_dtype = vec_dtype; p.rows = rows; p.cols = cols;
+  return launch_rowwise<true>(p, (hipStream_t)stream, "wanq_layernorm_rows");
+}
+
+extern "C" int wanq_gate_residual(const void* y, int y_dtype, const void* gate, int gate_dtype, int64_t gate_stride,
+                                  const void* residual, int res_dtype, void* out, int out_dtype, int64_t rows,
+                                  int cols, int64_t rows_per_batch, void* stream) {
+  WANQ_REQUIRE(y && gate && residual && out, WANQ_E_ARG, "wanq_gate_residual: NULL pointer");
+  WANQ_REQUIRE(is_fp(y_dtype) && is_fp(gate_dtype) && is_fp(res_dtype) && is_fp(out_dtype), WANQ_E_ARG,
+               "wanq_gate_residual: bad dtype code");
+  WANQ_REQUIRE(rows_per_batch >= 1, WANQ_E_ARG, "wanq_gate_residual: rows_per_batch must be >= 1");
+  if (int e = check_rows_cols("wanq_gate_residual", rows, cols)) return e;
+  if (rows == 0) return WANQ_OK;
+  GateParams p{y, gate, residual, out, y_dtype, gate_dtype, res_dtype, out_dtype, gate_stride, rows_per_batch, rows, cols};
+  const int64_t total = rows * (cols / 8);
+  const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(gate_residual_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("wanq_gate_residual");
+}
+
+extern "C" int wanq_col_absmax(const void* x, int x_dtype, float* colmax, int64_t rows, int cols, void* stream) {
+  WANQ_REQUIRE(x && colmax, WANQ_E_ARG, "wanq_col_absmax: NULL pointer");
+  WANQ_REQUIRE(is_fp(x_dtype), WANQ_E_ARG, "wanq_col_absmax: bad dtype %d", x_dtype);
+  WANQ_REQUIRE(cols >= 8 && cols % 8 == 0, WANQ_E_SHAPE, "wanq_col_absmax: cols=%d must be a multiple of 8", cols);
+  WANQ_REQUIRE(rows >= 0 && rows < (1ll << 40), WANQ_E_SHAPE, "wanq_col_absmax: rows out of range");
+  if (rows == 0) return WANQ_OK;
+  const unsigned panels = (unsigned)((cols + 511) / 512);
+  // ~2048 workgroups in total, at least 64 rows each
+  int64_t slabs = 2048 / panels;
+  if (slabs < 1) slabs = 1;
+  int64_t rpb = (rows + slabs - 1) / slabs;
+  if (rpb < 64) rpb = 64;
+  slabs = (rows + rpb - 1) / rpb;
+  WANQ_REQUIRE(slabs <= 65535, WANQ_E_SHAPE, "wanq_col_absmax: too many row slabs");
+  dim3 grid(panels, (unsigned)slabs);
+  hipStream_t st = (hipStream_t)stream;
+  if (x_dtype == WANQ_F16) hipLaunchKernelGGL(col_absmax_kernel<F16>, grid, dim3(256), 0, st, x, colmax, rows, cols, (int)rpb);
+  else if (x_dtype == WANQ_BF16) hipLaunchKernelGGL(col_absmax_kernel<BF16>, grid, dim3(256), 0, st, x, colmax, rows, cols, (int)rpb);
+  else hipLaunchKernelGGL(col_absmax_kernel<F32>, grid, dim3(256), 0, st, x, colmax, rows, cols, (int)rpb);
+  return check_launch("wanq_col_absmax");
+}
+
+extern "C" int wanq_row_minmax(const void* w, int w_dtype, float* row_min, float* row_max, float* row_absmax,
+                               int64_t rows, int cols, void* stream) {
+  WANQ_REQUIRE(w && (row_min || row_max || row_absmax), WANQ_E_ARG, "wanq_row_minmax: NULL pointer");
+  WANQ_REQUIRE(is_fp(w_dtype), WANQ_E_ARG, "wanq_row_minmax: bad dtype %d", w_dtype);
+  if (int e = check_rows_cols("wanq_row_minmax", rows, cols)) return e;
+  if (rows == 0) return WANQ_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int chunks = cols / 8;
+  if (chunks <= 256)
+    hipLaunchKernelGGL((row_minmax_kernel<1, 4>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, w, w_dtype, row_min, row_max, row_absmax, rows, cols);
+  else
+    hipLaunchKernelGGL((row_minmax_kernel<4, 8>), dim3((unsigned)rows), dim3(256), 0, st, w, w_dtype, row_min, row_max, row_absmax, rows, cols);
+  return check_launch("wanq_row_minmax");
+}
+
+extern "C" int wanq_weight_quant(const void* w, int w_dtype, const float* delta, const float* zp, int qmin, int qmax,
+                                 int8_t* q8, float* deq, int64_t rows, int cols, void* stream) {
+  WANQ_REQUIRE(w && delta && zp && (q8 || deq), WANQ_E_ARG, "wanq_weight_quant: NULL pointer");
+  WANQ_REQUIRE(is_fp(w_dtype), WANQ_E_ARG, "wanq_weight_quant: bad dtype %d", w_dtype);
+  WANQ_REQUIRE(qmin < qmax && (!q8 || (qmin >= -128 && qmax <= 127)), WANQ_E_ARG, "wanq_weight_quant: bad clamp range [%d,%d]", qmin, qmax);
+  if (int e = check_rows_cols("wanq_weight_quant", rows, cols)) return e;
+  if (rows == 0) return WANQ_OK;
+  const int64_t total = rows * (cols / 8);
+  const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(weight_quant_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, w_dtype, delta, zp, qmin, qmax, q8, deq, rows, cols);
+  return check_launch("wanq_weight_quant");
+}

@@ -1,0 +1,162 @@
+// Shared device/host helpers for libwanq_hip (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/wanq_hip.h"
+
+namespace wanq {
+
+// ---------------------------------------------------------------- host-side error plumbing
+void set_error(const char* fmt, ...);  // runtime.hip
+
+#define WANQ_REQUIRE(cond, code, ...)   \
+  do {                                  \
+    if (!(cond)) {                      \
+      ::wanq::set_error(__VA_ARGS__);   \
+      return (code);                    \
+    }                                   \
+  } while (0)
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return WANQ_E_LAUNCH;
+  }
+  return WANQ_OK;
+}
+
+inline bool is_fp(int dt) { return dt == WANQ_F16 || dt == WANQ_BF16 || dt == WANQ_F32; }
+inline bool is_vec(int dt) { return dt == WANQ_F16 || dt == WANQ_F32; }
+
+// ---------------------------------------------------------------- device: wave64 reductions
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------- device: typed 8-element access
+struct F16 {};
+struct BF16 {};
+struct F32 {};
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+
+template <typename T>
+struct Io;
+
+template <>
+struct Io<F16> {
+  static constexpr int kBytes = 2;
+  __device__ static __forceinline__ void load8(const void* base, int64_t elem, float (&v)[8]) {
+    const uint4 r = *reinterpret_cast<const uint4*>(static_cast<const char*>(base) + elem * 2);
+    const __half2* h = reinterpret_cast<const __half2*>(&r);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float2 f = __half22float2(h[i]);
+      v[2 * i] = f.x;
+      v[2 * i + 1] = f.y;
+    }
+  }
+  __device__ static __forceinline__ void store8(void* base, int64_t elem, const float (&v)[8]) {
+    uint4 r;
+    __half2* h = reinterpret_cast<__half2*>(&r);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = __floats2half2_rn(v[2 * i], v[2 * i + 1]);
+    *reinterpret_cast<uint4*>(static_cast<char*>(base) + elem * 2) = r;
+  }
+};
+
+template <>
+struct Io<BF16> {
+  static constexpr int kBytes = 2;
+  __device__ static __forceinline__ void load8(const void* base, int64_t elem, float (&v)[8]) {
+    const uint4 r = *reinterpret_cast<const uint4*>(static_cast<const char*>(base) + elem * 2);
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(w[i] << 16);
+      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  __device__ static __forceinline__ void store8(void* base, int64_t elem, const float (&v)[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const __hip_bfloat16 lo = __float2bfloat16(v[2 * i]);      // plain casts: RNE, NaN-preserving
+      const __hip_bfloat16 hi = __float2bfloat16(v[2 * i + 1]);
+      w[i] = (uint32_t)(*reinterpret_cast<const uint16_t*>(&lo)) |
+             ((uint32_t)(*reinterpret_cast<const uint16_t*>(&hi)) << 16);
+    }
+    *reinterpret_cast<uint4*>(static_cast<char*>(base) + elem * 2) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+template <>
+struct Io<F32> {
+  static constexpr int kBytes = 4;
+  __device__ static __forceinline__ void load8(const void* base, int64_t elem, float (&v)[8]) {
+    const float4* p = reinterpret_cast<const float4*>(static_cast<const char*>(base) + elem * 4);
+    const float4 a = p[0], b = p[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  __device__ static __forceinline__ void store8(void* base, int64_t elem, const float (&v)[8]) {
+    float4* p = reinterpret_cast<float4*>(static_cast<char*>(base) + elem * 4);
+    p[0] = make_float4(v[0], v[1], v[2], v[3]);
+    p[1] = make_float4(v[4], v[5], v[6], v[7]);
+  }
+};
+
+// per-token / per-channel vectors: dtype chosen at run time (wave-uniform branch)
+__device__ __forceinline__ float vec_load(const void* p, int dt, int64_t i) {
+  return dt == WANQ_F32 ? static_cast<const float*>(p)[i] : __half2float(static_cast<const __half*>(p)[i]);
+}
+__device__ __forceinline__ void vec_store(void* p, int dt, int64_t i, float v) {
+  if (dt == WANQ_F32) static_cast<float*>(p)[i] = v;
+  else static_cast<__half*>(p)[i] = __float2half_rn(v);
+}
+
+__device__ __forceinline__ float gelu_tanh_f32(float x) {
+  // 0.5 x (1 + tanh(0.79788456 (x + 0.044715 x^3)))   (reference fused.cu:22-26, in fp32)
+  const float inner = 0.79788456f * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(inner));
+}
+
+// q = clamp(rne(x / s)) with IEEE fp32 division semantics, computed as a multiply by 1/s plus an exact
+// fallback: the product t = x*inv is within 1.8e-7*|t| of fl(x/s); only when t sits that close to a
+// .5 boundary can rint(t) differ from rint(fl(x/s)), and then the true division is evaluated.
+__device__ __forceinline__ int quant_div_rne(float x, float s, float inv) {
+  float t = x * inv;
+  const float fr = fabsf(t - truncf(t));
+  if (fabsf(fr - 0.5f) <= 4e-7f * fabsf(t) + 1e-30f) t = x / s;
+  const float r = rintf(t);
+  return (int)fminf(fmaxf(r, -128.f), 127.f);
+}
+
+__device__ __forceinline__ uint32_t pack4_i8(int a, int b, int c, int d) {
+  return (uint32_t)(a & 0xff) | ((uint32_t)(b & 0xff) << 8) | ((uint32_t)(c & 0xff) << 16) | ((uint32_t)(d & 0xff) << 24);
+}
+
+}  // namespace wanq

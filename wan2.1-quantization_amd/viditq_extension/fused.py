@@ -1,0 +1,200 @@
+"""`viditq_extension.fused` -- same functions as the reference pybind module
+(ViDiT-Q/kernels/csrc/fused/pybind.cpp:5-99), executed by libwanq_hip (csrc/rowwise.hip).
+
+Differences from the reference, all widenings:
+  * input / output may be fp16, bf16 or fp32 (reference: fp16 only); per-token vectors fp16 or fp32;
+  * any hidden size that is a multiple of 8 up to 16384 (reference: %128, <= 4096 threads*4 / 8192);
+  * statistics, modulation and the quantisation division are fp32 (reference: half2 modulate,
+    multiply by 127/amax) -- the int8 codes equal qdiff's DynamicQuantizer bit for bit;
+  * all-zero rows give scale 1e-6 and zeros (reference: inf/NaN scale).
+"""
+import torch
+
+from . import _C
+
+_FP = (torch.float16, torch.bfloat16, torch.float32)
+_VEC = (torch.float16, torch.float32)
+
+
+def _rows_cols(name, t):
+    _C.check_gpu(name, t)
+    _C.check_contig(name, t)
+    _C.check_dtype(name, t, *_FP)
+    cols = t.shape[-1]
+    return t.numel() // cols, cols
+
+
+def _check_vec(name, t, rows):
+    _C.check_gpu(name, t)
+    _C.check_contig(name, t)
+    _C.check_dtype(name, t, *_VEC)
+    _C.check_shape(name, t, rows)
+
+
+def _quant_rows(input, sum_output, scaling, act, static_amax):
+    rows, cols = _rows_cols("input", input)
+    _check_vec("scaling", scaling, rows)
+    if sum_output is not None:
+        _check_vec("sum_output", sum_output, rows)
+        if sum_output.dtype != scaling.dtype:
+            raise RuntimeError("sum_output and scaling must share a dtype")
+    _C.check_same_device(input, sum_output, scaling)
+    out = torch.empty(input.shape, dtype=torch.int8, device=input.device)
+    with torch.cuda.device(input.device):
+        _C.call("wanq_quant_rows", _C.ptr(input), _C.dt(input), _C.ptr(out), _C.ptr(scaling), _C.ptr(sum_output),
+                _C.dt(scaling), rows, cols, act, static_amax, _C.stream())
+    return out
+
+
+def quant_sum(input, sum_output, scaling):
+    """int8 = quant(input); writes per-row scale into `scaling`, dequantised row sum into `sum_output`."""
+    return _quant_rows(input, sum_output, scaling, 0, 0)
+
+
+def quant_sum_static(input, sum_output, scaling):
+    """Like quant_sum, but `scaling` is an INPUT holding the per-row absmax (reference fused.cu:84-86)."""
+    return _quant_rows(input, sum_output, scaling, 0, 1)
+
+
+def gelu_quant_sum(input, sum_output, scaling):
+    """tanh-GELU then quant_sum."""
+    return _quant_rows(input, sum_output, scaling, 1, 0)
+
+
+def _layernorm(output, input, weight, shift_msa, scale_msa, sum_output, scaling, epsilon, quant):
+    rows, cols = _rows_cols("input", input)
+    _C.check_gpu("output", output)
+    _C.check_contig("output", output)
+    if output.numel() != input.numel():
+        raise RuntimeError("Tensor output must have as many elements as input")
+    batch, mod_stride, mod_dtype = 1, 0, _C.F32
+    mods = [weight, shift_msa, scale_msa]
+    present = [m for m in mods if m is not None]
+    if present:
+        md = present[0].dtype if all(m.dtype == present[0].dtype for m in present) else torch.float32
+        _C.check_dtype("weight/shift/scale", present[0], *_FP)
+        mod_dtype = _C.dt(md)
+        if weight is not None:
+            _C.check_gpu("weight", weight)
+            _C.check_shape("weight", weight, cols)
+            weight = weight.to(md).contiguous()
+        if shift_msa is not None or scale_msa is not None:
+            ref = shift_msa if shift_msa is not None else scale_msa
+            if ref.dim() != 2 or ref.shape[1] != cols:
+                raise RuntimeError(f"shift_msa/scale_msa must have shape (batch, {cols})")
+            batch = ref.shape[0]
+            if rows % batch:
+                raise RuntimeError("rows must be a multiple of the modulation batch size")
+
+            def prep(name, m):
+                if m is None:
+                    return None
+                _C.check_gpu(name, m)
+                _C.check_shape(name, m, batch, cols)
+                m = m.to(md)
+                return m if m.stride(1) == 1 else m.contiguous()
+
+            shift_msa, scale_msa = prep("shift_msa", shift_msa), prep("scale_msa", scale_msa)
+            strides = {m.stride(0) for m in (shift_msa, scale_msa) if m is not None}
+            if len(strides) > 1:
+                shift_msa, scale_msa = shift_msa.contiguous(), scale_msa.contiguous()
+            mod_stride = (shift_msa if shift_msa is not None else scale_msa).stride(0)
+    q = scale_p = sum_p = out_fp = None
+    vec_dt, out_dt = _C.F32, _C.F32
+    if quant:
+        _C.check_dtype("output", output, torch.int8)
+        _check_vec("scaling", scaling, rows)
+        if sum_output is not None:
+            _check_vec("sum_output", sum_output, rows)
+            if sum_output.dtype != scaling.dtype:
+                raise RuntimeError("sum_output and scaling must share a dtype")
+        q, scale_p, sum_p, vec_dt = _C.ptr(output), _C.ptr(scaling), _C.ptr(sum_output), _C.dt(scaling)
+    else:
+        _C.check_dtype("output", output, *_FP)
+        out_fp, out_dt = _C.ptr(output), _C.dt(output)
+    _C.check_same_device(input, output, weight, shift_msa, scale_msa, sum_output, scaling)
+    with torch.cuda.device(input.device):
+        _C.call("wanq_layernorm_rows", _C.ptr(input), _C.dt(input), _C.ptr(weight), _C.ptr(shift_msa), _C.ptr(scale_msa),
+                mod_dtype, mod_stride, rows // batch, float(epsilon), out_fp, out_dt, q, scale_p, sum_p, vec_dt,
+                rows, cols, _C.stream())
+
+
+def layernorm_nobias(out, input, weight, epsilon):
+    _layernorm(out, input, weight, None, None, None, None, epsilon, False)
+
+
+def layernorm_nobias_quant_nosum_fuse(out, input, weight, scaling, epsilon):
+    _layernorm(out, input, weight, None, None, None, scaling, epsilon, True)
+
+
+def layernorm_nobias_quant_sum_fuse(output, input, weight, sum_output, scaling, epsilon):
+    _layernorm(output, input, weight, None, None, sum_output, scaling, epsilon, True)
+
+
+def layernorm_nobias_t2i_fuse(output, input, weight, shift_msa, scale_msa, epsilon):
+    _layernorm(output, input, weight, shift_msa, scale_msa, None, None, epsilon, False)
+
+
+def layernorm_nobias_t2i_quant_sum_fuse(output, input, weight, shift_msa, scale_msa, sum_output, scaling, epsilon):
+    _layernorm(output, input, weight, shift_msa, scale_msa, sum_output, scaling, epsilon, True)
+
+
+def gate_residual_fuse(input, gate_msa, residual, out_dtype=None):
+    """input * gate_msa[b] + residual.  input/residual: [batch*tokens, hidden]; gate_msa: [batch, hidden]."""
+    rows, cols = _rows_cols("input", input)
+    _rows_cols("residual", residual)
+    _C.check_gpu("gate_msa", gate_msa)
+    _C.check_dtype("gate_msa", gate_msa, *_FP)
+    if gate_msa.dim() != 2 or gate_msa.shape[1] != cols:
+        raise RuntimeError(f"Tensor gate_msa must have shape (batch, {cols})")
+    if gate_msa.stride(1) != 1:
+        raise RuntimeError("Tensor gate_msa must be contiguous at the last dimension")
+    batch = gate_msa.shape[0]
+    if residual.numel() != input.numel() or rows % batch:
+        raise RuntimeError("input, residual and gate_msa shapes do not agree")
+    _C.check_same_device(input, gate_msa, residual)
+    out = torch.empty(input.shape, dtype=out_dtype or input.dtype, device=input.device)
+    with torch.cuda.device(input.device):
+        _C.call("wanq_gate_residual", _C.ptr(input), _C.dt(input), _C.ptr(gate_msa), _C.dt(gate_msa), gate_msa.stride(0),
+                _C.ptr(residual), _C.dt(residual), _C.ptr(out), _C.dt(out), rows, cols, rows // batch, _C.stream())
+    return out
+
+
+# ---- calibration / PTQ reductions (no counterpart in the reference extension; they replace torch
+#      reductions in get_calib_data_wanx.py:262-263 and qdiff/base/base_quantizer.py:70-90)
+def col_absmax_(running_max, x):
+    """running_max[c] = max(running_max[c], max_r |x[r,c]|) in place; running_max: fp32 [C]."""
+    rows, cols = _rows_cols("x", x)
+    _C.check_gpu("running_max", running_max)
+    _C.check_dtype("running_max", running_max, torch.float32)
+    _C.check_contig("running_max", running_max)
+    _C.check_shape("running_max", running_max, cols)
+    _C.check_same_device(x, running_max)
+    with torch.cuda.device(x.device):
+        _C.call("wanq_col_absmax", _C.ptr(x), _C.dt(x), _C.ptr(running_max), rows, cols, _C.stream())
+    return running_max
+
+
+def row_minmax(w):
+    """(min, max, absmax) per row of a 2-D weight, fp32."""
+    rows, cols = _rows_cols("w", w)
+    o = torch.empty(3, rows, dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _C.call("wanq_row_minmax", _C.ptr(w), _C.dt(w), _C.ptr(o[0]), _C.ptr(o[1]), _C.ptr(o[2]), rows, cols, _C.stream())
+    return o[0], o[1], o[2]
+
+
+def weight_quant(w, delta, zero_point, qmin, qmax, want_int8=True, want_dequant=False):
+    """Static per-row quantisation with given fp32 params; returns (int8 codes | None, fp32 fake-quant | None)."""
+    rows, cols = _rows_cols("w", w)
+    for n, t in (("delta", delta), ("zero_point", zero_point)):
+        _C.check_gpu(n, t)
+        _C.check_dtype(n, t, torch.float32)
+        _C.check_contig(n, t)
+        _C.check_shape(n, t, rows)
+    q8 = torch.empty(w.shape, dtype=torch.int8, device=w.device) if want_int8 else None
+    dq = torch.empty(w.shape, dtype=torch.float32, device=w.device) if want_dequant else None
+    with torch.cuda.device(w.device):
+        _C.call("wanq_weight_quant", _C.ptr(w), _C.dt(w), _C.ptr(delta), _C.ptr(zero_point), int(qmin), int(qmax),
+                _C.ptr(q8), _C.ptr(dq), rows, cols, _C.stream())
+    return q8, dq

@@ -1,0 +1,109 @@
+"""`viditq_extension.qgemm` -- same functions as the reference pybind module
+(ViDiT-Q/kernels/csrc/qgemm/pybind.cpp:5-12), executed by the int8-MFMA kernel in csrc/gemm_w8a8.hip.
+
+Widenings: any M (ragged last tile in-kernel), N % 8 == 0, K % 16 == 0 (reference: M,N % 128, K % 64, and a
+C assert that aborts the process otherwise); per-token / per-channel vectors fp16 or fp32; zero point
+int16 or fp32; output fp16 (reference), bf16 or fp32; launched on the CURRENT stream (reference: legacy
+default stream).
+"""
+import torch
+
+from . import _C
+
+_VEC = (torch.float16, torch.float32)
+
+
+def _check_i8(name, t, rows=None, cols=None):
+    _C.check_gpu(name, t)
+    _C.check_contig(name, t)
+    _C.check_dtype(name, t, torch.int8)
+    if t.dim() != 2:
+        raise RuntimeError(f"Tensor {name} must have dimension number (2)")
+    if rows is not None:
+        _C.check_shape(name, t, rows, cols)
+
+
+def _check_vec(name, t, n, dtypes=_VEC):
+    if t is None:
+        return
+    _C.check_gpu(name, t)
+    _C.check_contig(name, t)
+    _C.check_dtype(name, t, *dtypes)
+    _C.check_shape(name, t, n)
+
+
+def w8a8_linear(input, weight, scale_input, scale_weight, bias=None, input_sum=None, zp_weight=None,
+                out_dtype=torch.float16, gelu=False, gate=None, residual=None, out=None):
+    """General entry: y = epilogue(int8 input[M,K] @ int8 weight[N,K]^T); see include/wanq_hip.h.
+
+    gate (fp32 [N]) + residual ([M,N], out dtype): y = residual + y * gate (may alias `out`)."""
+    _check_i8("input", input)
+    M, K = input.shape
+    _check_i8("weight", weight)
+    N = weight.shape[0]
+    _C.check_shape("weight", weight, N, K)
+    _check_vec("scale_input", scale_input, M)
+    _check_vec("scale_weight", scale_weight, N)
+    _check_vec("bias", bias, N)
+    _check_vec("input_sum", input_sum, M)
+    _check_vec("zp_weight", zp_weight, N, (torch.int16, torch.float32))
+    if input_sum is not None and input_sum.dtype != scale_input.dtype:
+        raise RuntimeError("input_sum and scale_input must share a dtype")
+    if bias is not None and bias.dtype != scale_weight.dtype:
+        raise RuntimeError("bias and scale_weight must share a dtype")
+    if zp_weight is not None and input_sum is None:
+        raise RuntimeError("asymmetric weights (zp_weight) need input_sum")
+    epi = _C.EPI_GELU if gelu else 0
+    if gate is not None or residual is not None:
+        if gate is None or residual is None:
+            raise RuntimeError("gate and residual must be given together")
+        _check_vec("gate", gate, N, (torch.float32,))
+        _C.check_gpu("residual", residual)
+        _C.check_contig("residual", residual)
+        _C.check_dtype("residual", residual, out_dtype)
+        _C.check_shape("residual", residual, M, N)
+        epi |= _C.EPI_GATE_RES
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=input.device)
+    else:
+        _C.check_gpu("out", out)
+        _C.check_contig("out", out)
+        _C.check_dtype("out", out, out_dtype)
+        _C.check_shape("out", out, M, N)
+    _C.check_same_device(input, weight, scale_input, scale_weight, bias, input_sum, zp_weight, gate, residual, out)
+    with torch.cuda.device(input.device):
+        _C.call("wanq_gemm_w8a8", _C.ptr(input), _C.ptr(weight), _C.ptr(out), _C.dt(out_dtype), _C.ptr(scale_input),
+                _C.ptr(input_sum), _C.dt(scale_input), _C.ptr(scale_weight), _C.ptr(bias), _C.dt(scale_weight),
+                _C.ptr(zp_weight), _C.dt(zp_weight) if zp_weight is not None else _C.F32, _C.ptr(gate),
+                _C.ptr(residual), epi, M, N, K, _C.stream())
+    return out
+
+
+def w8a8_of16_bias_weight_asym(input, weight, bias, scale_input, scale_weight, input_sum, zp_weight):
+    """fp16( acc*sA*sB + sumA*zp*sB + bias )."""
+    return w8a8_linear(input, weight, scale_input, scale_weight, bias, input_sum, zp_weight)
+
+
+def w8a8_of16_bias_weight_sym(input, weight, bias, scale_input, scale_weight):
+    """fp16( acc*sA*sB + bias )."""
+    return w8a8_linear(input, weight, scale_input, scale_weight, bias)
+
+
+def w8a8_of16_nobias_weight_sym_qserve(input, weight, scale_input, scale_weight):
+    """fp16( acc*sW*sA ), no bias."""
+    return w8a8_linear(input, weight, scale_input, scale_weight)
+
+
+def w8a8_o32(input, weight):
+    """Raw int32 accumulators."""
+    _check_i8("input", input)
+    M, K = input.shape
+    _check_i8("weight", weight)
+    N = weight.shape[0]
+    _C.check_shape("weight", weight, N, K)
+    _C.check_same_device(input, weight)
+    out = torch.empty((M, N), dtype=torch.int32, device=input.device)
+    with torch.cuda.device(input.device):
+        _C.call("wanq_gemm_w8a8", _C.ptr(input), _C.ptr(weight), _C.ptr(out), _C.I32, None, None, _C.F32, None, None,
+                _C.F32, None, _C.F32, None, None, 0, M, N, K, _C.stream())
+    return out
