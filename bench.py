@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoising steps/s of the W8A8 Wan2.1-T2V-1.3B DiT at 832x480x81f on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One step = conditional DiT pass + unconditional DiT pass + classifier-free-guidance combine + scheduler update
+(ViDiT-Q/examples/Wan2.1/wan/text2video.py:248-269) on synthetic latents / text context / random-init weights
+of the named architecture, all resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "wan2.1-quantization_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+INT8_MFMA_PEAK = 5.03e15  # dense int8 op/s: 2048 op/clk/SIMD x 4 SIMD x 256 CU x 2.4 GHz (MI355X_MICROARCH.md, Matrix cores)
+
+
+def synth_model(name, device, seed=0):
+    """Random-init Wan backbone of the named architecture (xavier Linear as init_weights, small random biases,
+    non-zero head) -- SURVEY 8(d) synthetic-input recipe."""
+    from wan.configs import model_kwargs
+    from wan.modules.model import WanModel
+
+    torch.manual_seed(seed)
+    with torch.device(device):
+        m = WanModel(**model_kwargs(name))
+    g = torch.Generator(device=device).manual_seed(seed)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Linear) and mod.bias is not None:
+            mod.bias.data.normal_(std=0.02, generator=g)
+    torch.nn.init.xavier_uniform_(m.head.head.weight, generator=g)
+    return m.eval()
+
+
+class GemmTimer(list):
+    """Collects (start_event, end_event, int8_ops) for every W8A8 GEMM launch in the timed region."""
+
+    def summary(self):
+        if not self:
+            return None
+        t = sum(s.elapsed_time(e) for s, e, _ in self) * 1e-3
+        ops = float(sum(o for _, _, o in self))
+        return dict(launches=len(self), seconds=t, ops=ops)
+
+
+def cpu_baseline(cfg, L, rows=1024, reps=3):
+    """Reference fake-quant path (oracle/wan_ref.py, torch-CPU fp32) on a bounded slice of the SAME workload:
+    `rows` query tokens of one DiT block at sequence length L (all ten fake-quant Linears on those tokens, fp32
+    attention of rows x L keys), scaled by L/rows x blocks x 2 passes to one denoising step."""
+    from oracle import wan_ref as wr
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    cores = max(1, min(cores, 64))
+    torch.set_num_threads(cores)
+    C, Fd, H = cfg["dim"], cfg["ffn_dim"], cfg["num_heads"]
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for n in wr.LINEARS:
+        o, i = (Fd, C) if n == "ffn.0" else (C, Fd) if n == "ffn.2" else (C, C)
+        sd[n + ".weight"] = torch.randn(o, i, generator=g) * (2.0 / (i + o)) ** 0.5
+        sd[n + ".bias"] = torch.zeros(o)
+    for n in ("self_attn.norm_q", "self_attn.norm_k", "cross_attn.norm_q", "cross_attn.norm_k"):
+        sd[n + ".weight"] = torch.ones(C)
+    sd["norm3.weight"], sd["norm3.bias"], sd["modulation"] = torch.ones(C), torch.zeros(C), torch.randn(1, 6, C, generator=g) / C ** 0.5
+    blk = wr.block_from_state(sd, H, quant=True)
+    d = C // H
+    x = torch.randn(rows, C, generator=g)
+    e0 = torch.randn(1, 6, C, generator=g) * 0.1
+    ctx = torch.randn(512, C, generator=g)
+    kf = torch.randn(L, H, d, generator=g)
+    vf = torch.randn(L, H, d, generator=g)
+    freqs = wr.rope_freqs(d)
+    grid = (1, 16, rows // 16)
+
+    def slice_pass():
+        # self-attention of the slice against full-length keys/values, then the rest of the block on the slice
+        e = [t.reshape(1, C) for t in (blk.mod + e0).chunk(6, dim=1)]
+        h = wr.layer_norm(x, blk.eps) * (1 + e[1]) + e[0]
+        q = wr.rms_norm(blk.lin["self_attn.q"](h), blk.norm_w["self_attn.norm_q"], blk.eps).view(rows, H, d)
+        k = wr.rms_norm(blk.lin["self_attn.k"](h), blk.norm_w["self_attn.norm_k"], blk.eps).view(rows, H, d)
+        v = blk.lin["self_attn.v"](h).view(rows, H, d)
+        q, k = wr.rope_apply(q, grid, freqs), wr.rope_apply(k, grid, freqs)
+        kf[:rows], vf[:rows] = k, v
+        o = wr.attention(q, kf, vf).reshape(rows, C)
+        y = x + blk.lin["self_attn.o"](o) * e[2]
+        h = wr.layer_norm(y, blk.eps, *blk.norm3)
+        q = wr.rms_norm(blk.lin["cross_attn.q"](h), blk.norm_w["cross_attn.norm_q"], blk.eps).view(rows, H, d)
+        kc = wr.rms_norm(blk.lin["cross_attn.k"](ctx), blk.norm_w["cross_attn.norm_k"], blk.eps).view(-1, H, d)
+        vc = blk.lin["cross_attn.v"](ctx).view(-1, H, d)
+        y = y + blk.lin["cross_attn.o"](wr.attention(q, kc, vc).reshape(rows, C))
+        h = wr.layer_norm(y, blk.eps) * (1 + e[4]) + e[3]
+        return y + blk.lin["ffn.2"](torch.nn.functional.gelu(blk.lin["ffn.0"](h), approximate="tanh")) * e[5]
+
+    slice_pass()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        slice_pass()
+        ts.append(time.perf_counter() - t0)
+    t_slice = sorted(ts)[len(ts) // 2]
+    step_s = t_slice * (L / rows) * cfg["num_layers"] * 2
+    return dict(value=1.0 / step_s, unit="steps/s", cores=cores, kind="port",
+                sample=f"{rows}-token row slice of one fake-quant DiT block at L={L} (10 fake-quant Linears + fp32 attention "
+                       f"{rows}x{L}x{H} heads), median of {reps}: {t_slice:.3f}s, scaled x{L / rows:.1f} x{cfg['num_layers']} blocks x2 passes")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="t2v-1.3B")
+    ap.add_argument("--size", default="832*480")
+    ap.add_argument("--frames", type=int, default=81)
+    ap.add_argument("--guide", type=float, default=5.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-quality", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the quantized hot path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+
+    from viditq_extension import qgemm
+    from wan.configs import SIZE_CONFIGS, WAN_CONFIGS, latent_shape, seq_len_for
+    from wan.quant_wanx_hip import QuantWanModelHip
+    from wan.utils.fm_solvers import FlowMatchScheduler
+
+    cfg = WAN_CONFIGS[args.model]
+    shape = latent_shape(SIZE_CONFIGS[args.size], args.frames)
+    seq_len = seq_len_for(shape)
+    torch.backends.cuda.matmul.allow_tf32 = False
+
+    fp = synth_model(args.model, dev, seed=0)
+    model = QuantWanModelHip(fp, n_bits=8, sym=False, keep_fp_blocks=not args.no_quality)
+
+    g = torch.Generator(device=dev).manual_seed(42)
+    latent0 = torch.randn(shape, generator=g, device=dev)
+    ctx_c = torch.randn(512, cfg["text_dim"], generator=g, device=dev) * 0.1
+    ctx_u = torch.randn(512, cfg["text_dim"], generator=g, device=dev) * 0.1
+    total = args.steps + args.warmup
+    sched = FlowMatchScheduler(cfg["num_train_timesteps"], shift=1.0)
+    sched.set_timesteps(max(total, 30), device=dev, shift=5.0)
+
+    def step(latent, i):
+        t = sched.timesteps[i:i + 1]
+        cond = model([latent], t, [ctx_c], seq_len)[0]
+        uncond = model([latent], t, [ctx_u], seq_len)[0]
+        noise = uncond + args.guide * (cond - uncond)
+        return sched.step(noise, latent)
+
+    latent = latent0
+    for i in range(args.warmup):
+        latent = step(latent, i)
+    timer = GemmTimer()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    qgemm.set_timer(timer)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        latent = step(latent, i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    qgemm.set_timer(None)
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    assert torch.isfinite(latent).all(), "non-finite latent after the timed steps"
+
+    gs = timer.summary()
+    out = {
+        "metric": "denoising steps/sec Wan2.1-1.3B W8A8 832x480x81f", "value": args.steps / dt, "unit": "steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
+        "config": {"workload": f"Wan2.1-{args.model} DiT, W8A8 all block linears (W asym per-channel static, A sym per-token dynamic), "
+                               f"{args.size}x{args.frames}f, latent {list(shape)}, L={seq_len}, cond+uncond+CFG+scheduler per step",
+                   "attention": "bf16", "parallelism": f"sp{world}"},
+    }
+    if gs:
+        ach = gs["ops"] / gs["seconds"]
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_w8a8_kernel (int8 MFMA, all W8A8 linears)", "achieved": ach / 1e12,
+                           "peak": INT8_MFMA_PEAK / 1e12, "unit": "TOP/s", "frac": ach / INT8_MFMA_PEAK, "traffic": None,
+                           "launches": gs["launches"], "avg_launch_us": gs["seconds"] / gs["launches"] * 1e6,
+                           "gemm_share_of_step": gs["seconds"] / dt}
+    if rank == 0 and not args.no_quality:
+        # deviation of the quantized DiT output from the FP (bf16-autocast) output of the same synthetic model
+        t = sched.timesteps[0:1]
+        with torch.no_grad():
+            yq = model([latent0], t, [ctx_c], seq_len)[0]
+            model.fp.blocks = model.fp_blocks
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                yf = model.fp([latent0], t, [ctx_c], seq_len)[0]
+        mse = (yq - yf).pow(2).mean().item()
+        rng = (yf.max() - yf.min()).item()
+        out["quality"] = {"tensor": "DiT output latent (noise_pred)", "rel_l2_vs_fp": ((yq - yf).norm() / yf.norm()).item(),
+                          "psnr_db_vs_fp": 10 * torch.log10(torch.tensor(rng * rng / mse)).item()}
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, seq_len)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

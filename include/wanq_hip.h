@@ -115,6 +115,18 @@ int wanq_row_minmax(const void* w, int w_dtype, float* row_min, float* row_max, 
 int wanq_weight_quant(const void* w, int w_dtype, const float* delta, const float* zp, int qmin, int qmax,
                       int8_t* q8, float* deq, int64_t rows, int cols, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Attention front-end for q / k:  y = x * rsqrt(mean(x^2) + eps) * weight   (RMSNorm over ALL cols),
+ * then the 3-axis rotary embedding per head: pairs (2i, 2i+1) of every head are multiplied by
+ * (cos + i sin) from rope[pos, i] with pos = row % rows_per_batch; rows with pos >= positions (sequence
+ * padding) are left unrotated.  weight fp32[cols] or NULL (rope only); rope fp32[positions, head_dim/2, 2]
+ * or NULL (norm only).  In place (out == x) is allowed.
+ * Replaces WanRMSNorm.forward + rope_apply (ViDiT-Q/examples/Wan2.1/wan/modules/model.py:43-89), which the
+ * reference evaluates with several torch passes and a float64 complex multiply. */
+int wanq_rmsnorm_rope(const void* x, int x_dtype, const float* weight, const float* rope, void* out,
+                      int out_dtype, int64_t rows, int cols, int head_dim, int64_t rows_per_batch,
+                      int64_t positions, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,163 @@
+"""CPU oracle for the DiT block: torch-CPU fp32 restatement of the reference's SIMULATION path -- the FP
+WanAttentionBlock (W/wan/modules/model.py:293-370) with every block Linear replaced by qdiff's
+QuantizedLinear / ViDiTQuantizedLinear fake-quant forward (Q/base/quant_layer.py:57-74,
+Q/viditq/viditq_quant_layer.py:52-73), fp32 everywhere (no autocast), exact softmax attention.
+
+TEST INFRASTRUCTURE ONLY.  Also the `cpu_baseline` of bench.py (kind "port"): it is what the reference's
+fake-quant path costs on host cores.
+
+Parity status: the quantizers used here are the golden-pinned ones of oracle/qdiff_ref.py (restated with
+torch ops so the block runs in reasonable time; tests/test_oracle_golden.py::test_torch_quantizers_match_numpy
+ties the two together).  The surrounding FP block is restated from the reference source; the reference's own
+wan package cannot be imported here (needs diffusers/flash_attn/xfuser...), and attention has no fixture in
+the reference, so the block level is pinned by construction + the fp32 softmax definition only.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ---------------------------------------------------------------- quantizers (torch restatement of qdiff_ref)
+def dyn_fake_quant(x, n_bits=8):
+    """DynamicQuantizer.forward, sym (Q/base/base_quantizer.py:116-128,154-161).  x: [T, C] fp32."""
+    n = 2 ** (n_bits - 1) - 1
+    delta = x.abs().amax(dim=1, keepdim=True) / n
+    delta = torch.where(delta < 1e-6, torch.full_like(delta, 1e-6), delta)
+    return torch.clamp(torch.round(x / delta), -n - 1, n) * delta
+
+
+def static_params(w, n_bits=8, sym=False):
+    """StaticQuantizer.init_quant_params (Q/base/base_quantizer.py:70-99)."""
+    if sym:
+        return (w.abs().amax(dim=1) / (2 ** (n_bits - 1) - 1)).unsqueeze(1), torch.zeros(w.shape[0], 1)
+    n_levels = 2 ** n_bits
+    hi = w.amax(dim=1).clamp_min(0.0)
+    lo = w.amin(dim=1).clamp_max(0.0)
+    delta = (hi - lo) / (n_levels - 1)
+    zp = torch.round(lo / delta) + n_levels / 2
+    return delta.unsqueeze(1), zp.unsqueeze(1)
+
+
+def static_fake_quant(w, n_bits=8, sym=False):
+    """StaticQuantizer.forward (Q/base/base_quantizer.py:56-68)."""
+    delta, zp = static_params(w, n_bits, sym)
+    n = (2 ** (n_bits - 1) - 1) if sym else 2 ** n_bits
+    q = torch.clamp(torch.round(w / delta) - zp, -n - 1, n)
+    return (q + zp) * delta
+
+
+class FakeQuantLinear:
+    """QuantizedLinear / ViDiTQuantizedLinear forward on a 2-D input."""
+
+    def __init__(self, weight, bias, w_bits=8, a_bits=8, w_sym=False, channel_mask=None, rotation=None):
+        self.bias = None if bias is None else bias.float()
+        self.mask, self.R = channel_mask, rotation
+        w = weight.float()
+        if channel_mask is None:
+            self.weight = static_fake_quant(w, w_bits, w_sym)  # quant_layer.py:38-39
+        else:  # viditq_quant_layer.py:40-50: quantise, rotate, quantise again
+            w1 = static_fake_quant(w / channel_mask.reshape(1, -1), w_bits, w_sym)
+            self.weight = static_fake_quant((w1.double() @ rotation).float(), w_bits, w_sym)
+        self.a_bits = a_bits
+
+    def __call__(self, x):
+        if self.mask is not None:  # viditq_quant_layer.py:62-63
+            x = ((x * self.mask.reshape(1, -1)).double() @ self.R).float()
+        return F.linear(dyn_fake_quant(x, self.a_bits), self.weight, self.bias)
+
+
+class FpLinear:
+    def __init__(self, weight, bias):
+        self.weight, self.bias = weight.float(), None if bias is None else bias.float()
+
+    def __call__(self, x):
+        return F.linear(x, self.weight, self.bias)
+
+
+# ---------------------------------------------------------------- FP pieces of the block
+def layer_norm(x, eps, weight=None, bias=None):
+    return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)  # WanLayerNorm (model.py:92-102)
+
+
+def rms_norm(x, weight, eps):
+    return x * torch.rsqrt(x.pow(2).mean(dim=-1, keepdim=True) + eps) * weight  # WanRMSNorm (model.py:73-89)
+
+
+def rope_freqs(head_dim, max_len=1024, theta=10000):
+    """WanModel.freqs (model.py:523-529) + rope_params (:31-40)."""
+    def rp(dim):
+        inv = 1.0 / torch.pow(theta, torch.arange(0, dim, 2, dtype=torch.float64) / dim)
+        ang = torch.outer(torch.arange(max_len, dtype=torch.float64), inv)
+        return torch.polar(torch.ones_like(ang), ang)
+
+    d = head_dim
+    return torch.cat([rp(d - 4 * (d // 6)), rp(2 * (d // 6)), rp(2 * (d // 6))], dim=1)
+
+
+def rope_apply(x, grid, freqs):
+    """rope_apply (model.py:43-70) for one sample; x [L, n, d] fp32, float64 complex rotation."""
+    f, h, w = grid
+    n_tok, c = f * h * w, x.shape[-1] // 2
+    parts = freqs.split([c - 2 * (c // 3), c // 3, c // 3], dim=1)
+    fi = torch.cat([parts[0][:f].view(f, 1, 1, -1).expand(f, h, w, -1), parts[1][:h].view(1, h, 1, -1).expand(f, h, w, -1),
+                    parts[2][:w].view(1, 1, w, -1).expand(f, h, w, -1)], dim=-1).reshape(n_tok, 1, c)
+    xc = torch.view_as_complex(x[:n_tok].double().reshape(n_tok, x.shape[1], c, 2))
+    return torch.cat([torch.view_as_real(xc * fi).flatten(2), x[n_tok:].double()]).float()
+
+
+def attention(q, k, v, k_len=None):
+    """softmax(q k^T / sqrt(d)) v per head, fp32 (what flash_attention computes, attention.py:24-130).
+    q [Lq, n, d], k/v [Lk, n, d]; keys at or beyond k_len are masked (k_lens, attention.py:78-80)."""
+    if k_len is not None:
+        k, v = k[:k_len], v[:k_len]
+    s = torch.einsum("qnd,knd->nqk", q, k) / math.sqrt(q.shape[-1])
+    return torch.einsum("nqk,knd->qnd", torch.softmax(s, dim=-1), v)
+
+
+class BlockRef:
+    """One WanAttentionBlock in simulation mode.  `lin` maps 'self_attn.q' ... 'ffn.2' to callables."""
+
+    def __init__(self, lin, norm_w, modulation, num_heads, eps=1e-6, norm3=None):
+        self.lin, self.norm_w, self.mod, self.n, self.eps, self.norm3 = lin, norm_w, modulation.float(), num_heads, eps, norm3
+
+    def __call__(self, x, e0, grid, seq_len, context, freqs):
+        """x [L, C], e0 [1, 6, C], context [Lc, C] -> x' [L, C]   (model.py:293-370 for B = 1)."""
+        L, C = x.shape
+        n, d = self.n, C // self.n
+        e = (self.mod + e0.float()).chunk(6, dim=1)
+        e = [t.reshape(1, C) for t in e]
+        h = layer_norm(x, self.eps) * (1 + e[1]) + e[0]
+        q = rms_norm(self.lin["self_attn.q"](h), self.norm_w["self_attn.norm_q"], self.eps).view(L, n, d)
+        k = rms_norm(self.lin["self_attn.k"](h), self.norm_w["self_attn.norm_k"], self.eps).view(L, n, d)
+        v = self.lin["self_attn.v"](h).view(L, n, d)
+        o = attention(rope_apply(q, grid, freqs), rope_apply(k, grid, freqs), v, seq_len).reshape(L, C)
+        x = x + self.lin["self_attn.o"](o) * e[2]
+        h = layer_norm(x, self.eps, *(self.norm3 or (None, None)))
+        q = rms_norm(self.lin["cross_attn.q"](h), self.norm_w["cross_attn.norm_q"], self.eps).view(L, n, d)
+        k = rms_norm(self.lin["cross_attn.k"](context), self.norm_w["cross_attn.norm_k"], self.eps).view(-1, n, d)
+        v = self.lin["cross_attn.v"](context).view(-1, n, d)
+        x = x + self.lin["cross_attn.o"](attention(q, k, v).reshape(L, C))
+        h = layer_norm(x, self.eps) * (1 + e[4]) + e[3]
+        y = self.lin["ffn.2"](F.gelu(self.lin["ffn.0"](h), approximate="tanh"))
+        return x + y * e[5]
+
+
+LINEARS = ("self_attn.q", "self_attn.k", "self_attn.v", "self_attn.o", "cross_attn.q", "cross_attn.k", "cross_attn.v",
+           "cross_attn.o", "ffn.0", "ffn.2")
+
+
+def block_from_state(sd, num_heads, eps=1e-6, quant=True, w_bits=8, a_bits=8, vidit=None):
+    """Build a BlockRef from a WanAttentionBlock state dict (CPU tensors).
+    vidit: optional {linear name: (channel_mask fp32 [K], rotation fp64 [K,K])}."""
+    lin = {}
+    for name in LINEARS:
+        w, b = sd[name + ".weight"], sd.get(name + ".bias")
+        if quant:
+            cm, R = (vidit or {}).get(name, (None, None))
+            lin[name] = FakeQuantLinear(w, b, w_bits, a_bits, False, cm, R)
+        else:
+            lin[name] = FpLinear(w, b)
+    norm_w = {k: sd[k + ".weight"].float() for k in ("self_attn.norm_q", "self_attn.norm_k", "cross_attn.norm_q", "cross_attn.norm_k")}
+    norm3 = (sd["norm3.weight"].float(), sd["norm3.bias"].float()) if "norm3.weight" in sd else None
+    return BlockRef(lin, norm_w, sd["modulation"], num_heads, eps, norm3)

@@ -1,0 +1,110 @@
+"""GPU parity of the attention front-end and of the whole kernel-mode DiT block against the CPU oracle of
+the reference's simulation path (oracle/wan_ref.py).
+
+Tolerance of the block test (stated): activations between kernels are bf16 (8 significant bits)
+where the oracle is fp32, and every re-quantisation to int8 can move a code by one step when its fp input
+moves by a bf16 ulp.  Measured against the oracle the block output's relative Frobenius error is ~3e-3; the
+test allows 1e-2, and additionally demands that the kernel-mode block is much closer to the fake-quant
+oracle than the quantisation error itself (distance oracle_quant <-> oracle_fp)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import wan_ref as wr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm()).item()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_rmsnorm_rope_vs_oracle(dtype):
+    from wan import ops
+
+    n, d = 3, 128
+    grid = (3, 5, 7)
+    L = 3 * 5 * 7 + 6  # 6 padding rows stay unrotated
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(L, n * d, generator=g).to(dtype)
+    w = torch.rand(n * d, generator=g) + 0.5
+    freqs = wr.rope_freqs(d)
+    ref = wr.rope_apply(wr.rms_norm(x.float(), w, 1e-6).view(L, n, d), grid, freqs).reshape(L, n * d)
+    table = ops.rope_table(freqs, grid, DEV)
+    assert table.shape == (105, 64, 2)
+    y = ops.rmsnorm_rope_(x.to(DEV).clone(), w.to(DEV), table, d, eps=1e-6)
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-6
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.numpy(), rtol=tol, atol=tol)
+    # norm only / rope only
+    y = ops.rmsnorm_rope_(x.to(DEV).clone(), w.to(DEV), None, d, eps=1e-6)
+    np.testing.assert_allclose(y.float().cpu().numpy(), wr.rms_norm(x.float(), w, 1e-6).numpy(), rtol=tol, atol=tol)
+    y = ops.rmsnorm_rope_(x.to(DEV).clone(), None, table, d)
+    np.testing.assert_allclose(y.float().cpu().numpy(), wr.rope_apply(x.float().view(L, n, d), grid, freqs).reshape(L, -1).numpy(),
+                               rtol=tol, atol=tol)
+
+
+def make_block(dim, ffn, heads, seed):
+    from wan.modules.model import WanAttentionBlock
+
+    torch.manual_seed(seed)
+    blk = WanAttentionBlock("t2v_cross_attn", dim, ffn, heads, cross_attn_norm=True)
+    for m in blk.modules():
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.xavier_uniform_(m.weight)
+            torch.nn.init.normal_(m.bias, std=0.05)
+    blk.norm3.weight.data.uniform_(0.5, 1.5)
+    blk.norm3.bias.data.normal_(std=0.1)
+    for nm in (blk.self_attn.norm_q, blk.self_attn.norm_k, blk.cross_attn.norm_q, blk.cross_attn.norm_k):
+        nm.weight.data.uniform_(0.5, 1.5)
+    return blk
+
+
+@pytest.mark.parametrize("dim,ffn,heads,grid,pad,lc", [(256, 512, 2, (3, 6, 10), 4, 40), (1536, 8960, 12, (2, 6, 8), 0, 64)])
+def test_kernel_mode_block_vs_simulation_oracle(dim, ffn, heads, grid, pad, lc):
+    from wan import ops
+    from wan.quant_wanx_hip import WanAttentionBlockWithHipKernel
+
+    blk = make_block(dim, ffn, heads, 0)
+    sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    n_tok = grid[0] * grid[1] * grid[2]
+    L = n_tok + pad
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(L, dim, generator=g)
+    x[:, 5] *= 12.0  # an outlier channel, as real DiT activations have
+    x[n_tok:] = 0
+    e0 = torch.randn(1, 6, dim, generator=g) * 0.3
+    ctx = torch.randn(lc, dim, generator=g)
+    freqs = wr.rope_freqs(dim // heads)
+
+    ref_q = wr.block_from_state(sd, heads, quant=True)(x, e0, grid, n_tok, ctx, freqs)
+    ref_fp = wr.block_from_state(sd, heads, quant=False)(x, e0, grid, n_tok, ctx, freqs)
+
+    hb = WanAttentionBlockWithHipKernel.from_float(blk.to(DEV))
+    xd = x.to(DEV).clone()
+    cq = WanAttentionBlockWithHipKernel._quant(ctx.to(DEV))
+    out = hb(xd, e0.to(DEV), ops.rope_table(freqs, grid, DEV), n_tok, cq)
+    assert out.data_ptr() == xd.data_ptr()  # residual stream updated in place
+    got = out.float().cpu()[:n_tok]
+
+    err_q = rel_err(got, ref_q[:n_tok])
+    quant_noise = rel_err(ref_q[:n_tok], ref_fp[:n_tok])
+    print(f"dim={dim}: rel err vs fake-quant oracle {err_q:.2e}; fake-quant vs fp {quant_noise:.2e}")
+    assert err_q < 1e-2
+    assert err_q < 0.5 * quant_noise + 5e-3
+
+
+def test_weight_codes_and_params_match_oracle():
+    """HipLinearW8A8.from_float: delta / zero_point / dequantised weight identical to the oracle's."""
+    from wan.quant_wanx_hip import HipLinearW8A8
+
+    w = torch.randn(96, 256, generator=torch.Generator().manual_seed(4)) * 0.1
+    w[0] = w[0].abs()
+    w[1] = -w[1].abs()
+    hl = HipLinearW8A8.from_float(w.to(DEV), None)
+    delta, zp = wr.static_params(w)
+    assert torch.equal(hl.scale_weight.cpu(), delta.view(-1)) and torch.equal(hl.zp_weight.cpu(), zp.view(-1))
+    deq = (hl.weight.float().cpu() + zp) * delta
+    assert torch.equal(deq, wr.static_fake_quant(w))

@@ -169,3 +169,22 @@ def test_sim_and_kernel_modes_agree(golden):
     y_s = kr.fake_quant_linear_from_int(qa, da, qw, dw, zw, g["b"])
     np.testing.assert_allclose(y_k, y_s, rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(y_k, g["y"].reshape(y_k.shape), rtol=2e-5, atol=2e-5)
+
+
+def test_torch_quantizers_match_numpy(golden):
+    """oracle/wan_ref.py restates the quantizers with torch ops; they must equal the golden-pinned numpy ones."""
+    import torch
+
+    from oracle import wan_ref as wr
+
+    g = golden("a2_dynamic_32x1536")
+    assert np.array_equal(wr.dyn_fake_quant(torch.from_numpy(g["x"])).numpy(), g["dequant"])
+    g = golden("a1_static_12x1536")
+    assert np.array_equal(wr.static_fake_quant(torch.from_numpy(g["w"]), 8, False).numpy(), g["a8_dequant"])
+    assert np.array_equal(wr.static_fake_quant(torch.from_numpy(g["w"]), 4, False).numpy(), g["a4_dequant"])
+    g = golden("a4_viditq")
+    R = torch.from_numpy(qr.hadamard_from_signs(g["signs"]))
+    fl = wr.FakeQuantLinear(torch.from_numpy(g["w"]), torch.from_numpy(g["b"]), 8, 8, False, torch.from_numpy(g["channel_mask"]), R)
+    assert np.array_equal(fl.weight.numpy(), g["w_final"])
+    y = fl(torch.from_numpy(g["x"]).reshape(-1, g["x"].shape[-1])).numpy()
+    np.testing.assert_allclose(y, g["y"].reshape(y.shape), rtol=2e-5, atol=2e-5)

@@ -1,0 +1,122 @@
+// Attention front-end: RMSNorm over the full model dim (WanRMSNorm, wan/modules/model.py:73-89) fused with
+// the 3-axis rotary embedding (rope_apply, model.py:43-70) for q and k.  Row-wise, HBM-bound: a row is
+// read once, kept in registers across the sum-of-squares reduction, rotated, written once.
+//
+// rope table: fp32 [positions, head_dim/2, 2] = (cos, sin) per token position and complex pair; the host
+// builds it once per (F,H,W) grid in float64 (as the reference does its whole rotation) and rounds to fp32.
+// Rows at or beyond `positions` (sequence padding) are normalised but not rotated, as in the reference.
+#include "wanq_common.h"
+
+namespace wanq {
+
+struct PrepParams {
+  const void* x;
+  void* out;
+  const float* weight;
+  const float* rope;
+  int x_dtype, out_dtype;
+  int64_t rows, rows_per_batch, positions;
+  int cols, head_dim;
+  float eps;
+};
+
+__device__ __forceinline__ void prep_load8(const void* base, int dt, int64_t elem, float (&v)[8]) {
+  if (dt == WANQ_F16) Io<F16>::load8(base, elem, v);
+  else if (dt == WANQ_BF16) Io<BF16>::load8(base, elem, v);
+  else Io<F32>::load8(base, elem, v);
+}
+__device__ __forceinline__ void prep_store8(void* base, int dt, int64_t elem, const float (&v)[8]) {
+  if (dt == WANQ_F16) Io<F16>::store8(base, elem, v);
+  else if (dt == WANQ_BF16) Io<BF16>::store8(base, elem, v);
+  else Io<F32>::store8(base, elem, v);
+}
+
+template <int WPR, int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const PrepParams p) {
+  __shared__ float slots[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (WPR == 1) ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
+  if (WPR == 1 && row >= p.rows) return;
+  const int sub = (WPR == 1) ? 0 : wave;
+  const int C = p.cols;
+  const int64_t rbase = row * (int64_t)C;
+  float v[NCH][8];
+  bool ok[NCH];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c0 = (sub * 64 + lane + i * 64 * WPR) * 8;
+    ok[i] = c0 < C;
+    if (ok[i]) {
+      prep_load8(p.x, p.x_dtype, rbase + c0, v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
+    }
+  }
+  ss = wave_sum(ss);
+  if (WPR > 1) {
+    if (lane == 0) slots[wave] = ss;
+    __syncthreads();
+    ss = slots[0] + slots[1] + slots[2] + slots[3];
+  }
+  const float rinv = p.weight ? 1.0f / sqrtf(ss / (float)C + p.eps) : 1.0f;  // weight == NULL: rope only
+  const int64_t pos = row % p.rows_per_batch;
+  const bool rot = p.rope && pos < p.positions;
+  const int half = p.head_dim >> 1;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    if (!ok[i]) continue;
+    const int c0 = (sub * 64 + lane + i * 64 * WPR) * 8;
+    if (p.weight) {
+      float w[8];
+      Io<F32>::load8(p.weight, c0, w);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = v[i][j] * rinv * w[j];
+    }
+    if (rot) {
+      const int pair0 = (c0 % p.head_dim) >> 1;  // 4 consecutive complex pairs of one head
+      float cs[8];
+      Io<F32>::load8(p.rope, (pos * half + pair0) * 2, cs);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float a = v[i][2 * k], b = v[i][2 * k + 1];
+        v[i][2 * k] = a * cs[2 * k] - b * cs[2 * k + 1];
+        v[i][2 * k + 1] = a * cs[2 * k + 1] + b * cs[2 * k];
+      }
+    }
+    prep_store8(p.out, p.out_dtype, rbase + c0, v[i]);
+  }
+}
+
+}  // namespace wanq
+
+using namespace wanq;
+
+extern "C" int wanq_rmsnorm_rope(const void* x, int x_dtype, const float* weight, const float* rope, void* out,
+                                 int out_dtype, int64_t rows, int cols, int head_dim, int64_t rows_per_batch,
+                                 int64_t positions, float eps, void* stream) {
+  WANQ_REQUIRE(x && out, WANQ_E_ARG, "wanq_rmsnorm_rope: NULL pointer");
+  WANQ_REQUIRE(is_fp(x_dtype) && is_fp(out_dtype), WANQ_E_ARG, "wanq_rmsnorm_rope: bad dtype code");
+  WANQ_REQUIRE(weight || rope, WANQ_E_ARG, "wanq_rmsnorm_rope: nothing to do (weight and rope both NULL)");
+  WANQ_REQUIRE(cols >= 8 && cols % 8 == 0 && cols <= 16384, WANQ_E_SHAPE, "wanq_rmsnorm_rope: cols=%d must be a multiple of 8 in [8,16384]", cols);
+  WANQ_REQUIRE(!rope || (head_dim >= 8 && head_dim % 8 == 0 && cols % head_dim == 0), WANQ_E_SHAPE,
+               "wanq_rmsnorm_rope: head_dim=%d must be a multiple of 8 dividing cols=%d", head_dim, cols);
+  WANQ_REQUIRE(rows >= 0 && rows < (1ll << 31) && rows_per_batch >= 1, WANQ_E_SHAPE, "wanq_rmsnorm_rope: bad rows");
+  if (rows == 0) return WANQ_OK;
+  PrepParams p{x, out, weight, rope, x_dtype, out_dtype, rows, rows_per_batch, positions, cols, head_dim > 0 ? head_dim : 8, eps};
+  hipStream_t st = (hipStream_t)stream;
+  const int chunks = cols / 8;
+#define WANQ_PR(WPR, NCH) \
+  hipLaunchKernelGGL((rmsnorm_rope_kernel<WPR, NCH>), dim3((unsigned)((WPR) == 1 ? (rows + 3) / 4 : rows)), dim3(256), 0, st, p)
+  if (chunks <= 64) WANQ_PR(1, 1);
+  else if (chunks <= 128) WANQ_PR(1, 2);
+  else if (chunks <= 192) WANQ_PR(1, 3);
+  else if (chunks <= 256) WANQ_PR(1, 4);
+  else if (chunks <= 512) WANQ_PR(4, 2);
+  else if (chunks <= 768) WANQ_PR(4, 3);
+  else if (chunks <= 1024) WANQ_PR(4, 4);
+  else if (chunks <= 1536) WANQ_PR(4, 6);
+  else WANQ_PR(4, 8);
+#undef WANQ_PR
+  return check_launch("wanq_rmsnorm_rope");
+}

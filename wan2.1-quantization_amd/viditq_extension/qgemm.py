@@ -12,6 +12,15 @@ from . import _C
 
 _VEC = (torch.float16, torch.float32)
 
+_timer = None
+
+
+def set_timer(t):
+    """bench.py hook: when set to a list, every GEMM launch appends (start_event, end_event, int8 ops), the
+    events bracketing exactly that launch on the current stream."""
+    global _timer
+    _timer = t
+
 
 def _check_i8(name, t, rows=None, cols=None):
     _C.check_gpu(name, t)
@@ -72,10 +81,16 @@ def w8a8_linear(input, weight, scale_input, scale_weight, bias=None, input_sum=N
         _C.check_shape("out", out, M, N)
     _C.check_same_device(input, weight, scale_input, scale_weight, bias, input_sum, zp_weight, gate, residual, out)
     with torch.cuda.device(input.device):
+        if _timer is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         _C.call("wanq_gemm_w8a8", _C.ptr(input), _C.ptr(weight), _C.ptr(out), _C.dt(out_dtype), _C.ptr(scale_input),
                 _C.ptr(input_sum), _C.dt(scale_input), _C.ptr(scale_weight), _C.ptr(bias), _C.dt(scale_weight),
                 _C.ptr(zp_weight), _C.dt(zp_weight) if zp_weight is not None else _C.F32, _C.ptr(gate),
                 _C.ptr(residual), epi, M, N, K, _C.stream())
+        if _timer is not None:
+            ev1.record()
+            _timer.append((ev0, ev1, 2 * M * N * K))
     return out
 
 

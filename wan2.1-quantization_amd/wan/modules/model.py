@@ -1,0 +1,232 @@
+"""Wan2.1 DiT backbone (FP).  Same parameter names and forward semantics as
+ViDiT-Q/examples/Wan2.1/wan/modules/model.py (so Wan2.1 checkpoints and the reference's layer-name regexes
+apply unchanged), without diffusers / flash_attn: attention goes through wan.ops.attention, the rotary
+table is built once per grid, and the self-attention q path is the correct one (the reference's committed
+WanSelfAttention.forward drops norm_q and the head view -- SURVEY D1; semantics follow
+wan/distributed/xdit_context_parallel.py:162-170)."""
+import json
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+__all__ = ["WanModel", "WanAttentionBlock", "WanSelfAttention", "WanT2VCrossAttention", "WanRMSNorm", "WanLayerNorm",
+           "sinusoidal_embedding_1d", "rope_params", "rope_apply"]
+
+
+def sinusoidal_embedding_1d(dim, position):
+    """float64 sinusoid, cos half first (reference model.py:18-28)."""
+    half = dim // 2
+    pos = position.to(torch.float64)
+    ang = torch.outer(pos, torch.pow(10000, -torch.arange(half, dtype=torch.float64, device=pos.device) / half))
+    return torch.cat([ang.cos(), ang.sin()], dim=1)
+
+
+def rope_params(max_seq_len, dim, theta=10000):
+    """complex128 [max_seq_len, dim/2] (reference model.py:31-40)."""
+    inv = 1.0 / torch.pow(theta, torch.arange(0, dim, 2, dtype=torch.float64) / dim)
+    ang = torch.outer(torch.arange(max_seq_len, dtype=torch.float64), inv)
+    return torch.polar(torch.ones_like(ang), ang)
+
+
+def rope_apply(x, grid, freqs):
+    """Reference-semantics rotary embedding in float64 for ONE sample: x [L, n, d]; rows beyond f*h*w are
+    passed through (reference model.py:43-70).  Used by the FP torch path; the HIP path uses
+    ops.rmsnorm_rope_ with ops.rope_table."""
+    f, h, w = grid
+    n_tok = f * h * w
+    c = x.shape[-1] // 2
+    parts = freqs.split([c - 2 * (c // 3), c // 3, c // 3], dim=1)
+    fi = torch.cat([parts[0][:f].view(f, 1, 1, -1).expand(f, h, w, -1), parts[1][:h].view(1, h, 1, -1).expand(f, h, w, -1),
+                    parts[2][:w].view(1, 1, w, -1).expand(f, h, w, -1)], dim=-1).reshape(n_tok, 1, c).to(x.device)
+    xc = torch.view_as_complex(x[:n_tok].to(torch.float64).reshape(n_tok, x.shape[1], c, 2))
+    out = torch.view_as_real(xc * fi).flatten(2)
+    return torch.cat([out, x[n_tok:].to(torch.float64)]).float()
+
+
+class WanRMSNorm(nn.Module):
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.dim, self.eps = dim, eps
+        self.weight = nn.Parameter(torch.ones(dim))
+
+    def forward(self, x):
+        xf = x.float()
+        return (xf * torch.rsqrt(xf.pow(2).mean(dim=-1, keepdim=True) + self.eps)).type_as(x) * self.weight
+
+
+class WanLayerNorm(nn.LayerNorm):
+    def __init__(self, dim, eps=1e-6, elementwise_affine=False):
+        super().__init__(dim, elementwise_affine=elementwise_affine, eps=eps)
+
+    def forward(self, x):
+        return super().forward(x.float()).type_as(x)
+
+
+class WanSelfAttention(nn.Module):
+    def __init__(self, dim, num_heads, window_size=(-1, -1), qk_norm=True, eps=1e-6):
+        super().__init__()
+        assert dim % num_heads == 0
+        self.dim, self.num_heads, self.head_dim = dim, num_heads, dim // num_heads
+        self.window_size, self.qk_norm, self.eps = window_size, qk_norm, eps
+        self.q, self.k, self.v, self.o = (nn.Linear(dim, dim) for _ in range(4))
+        self.norm_q = WanRMSNorm(dim, eps=eps) if qk_norm else nn.Identity()
+        self.norm_k = WanRMSNorm(dim, eps=eps) if qk_norm else nn.Identity()
+
+    def forward(self, x, seq_lens, grid_sizes, freqs):
+        b, s, n, d = x.shape[0], x.shape[1], self.num_heads, self.head_dim
+        q = self.norm_q(self.q(x)).view(b, s, n, d)
+        k = self.norm_k(self.k(x)).view(b, s, n, d)
+        v = self.v(x).view(b, s, n, d)
+        outs = []
+        for i in range(b):
+            qi = rope_apply(q[i], grid_sizes[i], freqs).to(torch.bfloat16).flatten(1)
+            ki = rope_apply(k[i], grid_sizes[i], freqs).to(torch.bfloat16).flatten(1)
+            outs.append(ops.attention(qi, ki, v[i].to(torch.bfloat16).flatten(1), n, int(seq_lens[i])))
+        return self.o(torch.stack(outs))
+
+
+class WanT2VCrossAttention(WanSelfAttention):
+    def forward(self, x, context, context_lens):
+        b, n = x.shape[0], self.num_heads
+        q = self.norm_q(self.q(x))
+        k = self.norm_k(self.k(context))
+        v = self.v(context)
+        outs = [ops.attention(q[i].to(torch.bfloat16), k[i].to(torch.bfloat16), v[i].to(torch.bfloat16), n,
+                              None if context_lens is None else int(context_lens[i])) for i in range(b)]
+        return self.o(torch.stack(outs))
+
+
+class WanAttentionBlock(nn.Module):
+    def __init__(self, cross_attn_type, dim, ffn_dim, num_heads, window_size=(-1, -1), qk_norm=True,
+                 cross_attn_norm=False, eps=1e-6):
+        super().__init__()
+        assert cross_attn_type == "t2v_cross_attn", "only the T2V backbone is in scope"
+        self.dim, self.ffn_dim, self.num_heads, self.eps = dim, ffn_dim, num_heads, eps
+        self.norm1 = WanLayerNorm(dim, eps)
+        self.self_attn = WanSelfAttention(dim, num_heads, window_size, qk_norm, eps)
+        self.norm3 = WanLayerNorm(dim, eps, elementwise_affine=True) if cross_attn_norm else nn.Identity()
+        self.cross_attn = WanT2VCrossAttention(dim, num_heads, (-1, -1), qk_norm, eps)
+        self.norm2 = WanLayerNorm(dim, eps)
+        self.ffn = nn.Sequential(nn.Linear(dim, ffn_dim), nn.GELU(approximate="tanh"), nn.Linear(ffn_dim, dim))
+        self.modulation = nn.Parameter(torch.randn(1, 6, dim) / dim ** 0.5)
+
+    def forward(self, x, e, seq_lens, grid_sizes, freqs, context, context_lens):
+        """x [B, L, C] fp32 residual stream, e [B, 6, C] fp32 (reference model.py:293-370)."""
+        with torch.autocast("cuda", enabled=False):
+            e = (self.modulation.float() + e.float()).chunk(6, dim=1)
+        y = self.self_attn(self.norm1(x).float() * (1 + e[1]) + e[0], seq_lens, grid_sizes, freqs)
+        x = x + y.float() * e[2]
+        x = x + self.cross_attn(self.norm3(x), context, context_lens).float()
+        y = self.ffn(self.norm2(x).float() * (1 + e[4]) + e[3])
+        return x + y.float() * e[5]
+
+
+class Head(nn.Module):
+    def __init__(self, dim, out_dim, patch_size, eps=1e-6):
+        super().__init__()
+        self.dim, self.out_dim, self.patch_size, self.eps = dim, out_dim, patch_size, eps
+        self.norm = WanLayerNorm(dim, eps)
+        self.head = nn.Linear(dim, math.prod(patch_size) * out_dim)
+        self.modulation = nn.Parameter(torch.randn(1, 2, dim) / dim ** 0.5)
+
+    def forward(self, x, e):
+        with torch.autocast("cuda", enabled=False):
+            e = (self.modulation.float() + e.float().unsqueeze(1)).chunk(2, dim=1)
+            return self.head(self.norm(x.float()) * (1 + e[1]) + e[0])
+
+
+class WanModel(nn.Module):
+    """T2V diffusion backbone.  forward(x: list[C,F,H,W], t: [B], context: list[L,C], seq_len) -> list."""
+
+    def __init__(self, model_type="t2v", patch_size=(1, 2, 2), text_len=512, in_dim=16, dim=2048, ffn_dim=8192,
+                 freq_dim=256, text_dim=4096, out_dim=16, num_heads=16, num_layers=32, window_size=(-1, -1),
+                 qk_norm=True, cross_attn_norm=True, eps=1e-6):
+        super().__init__()
+        assert model_type == "t2v", "only the T2V backbone is in scope (SURVEY section 2.1)"
+        self.config = dict(model_type=model_type, patch_size=tuple(patch_size), text_len=text_len, in_dim=in_dim, dim=dim,
+                           ffn_dim=ffn_dim, freq_dim=freq_dim, text_dim=text_dim, out_dim=out_dim, num_heads=num_heads,
+                           num_layers=num_layers, window_size=tuple(window_size), qk_norm=qk_norm,
+                           cross_attn_norm=cross_attn_norm, eps=eps)
+        for k, v in self.config.items():
+            setattr(self, k, v)
+        self.patch_embedding = nn.Conv3d(in_dim, dim, kernel_size=self.patch_size, stride=self.patch_size)
+        self.text_embedding = nn.Sequential(nn.Linear(text_dim, dim), nn.GELU(approximate="tanh"), nn.Linear(dim, dim))
+        self.time_embedding = nn.Sequential(nn.Linear(freq_dim, dim), nn.SiLU(), nn.Linear(dim, dim))
+        self.time_projection = nn.Sequential(nn.SiLU(), nn.Linear(dim, dim * 6))
+        self.blocks = nn.ModuleList([WanAttentionBlock("t2v_cross_attn", dim, ffn_dim, num_heads, window_size, qk_norm,
+                                                       cross_attn_norm, eps) for _ in range(num_layers)])
+        self.head = Head(dim, out_dim, self.patch_size, eps)
+        d = dim // num_heads
+        assert dim % num_heads == 0 and d % 2 == 0
+        self.freqs = torch.cat([rope_params(1024, d - 4 * (d // 6)), rope_params(1024, 2 * (d // 6)),
+                                rope_params(1024, 2 * (d // 6))], dim=1)
+        self.init_weights()
+
+    # ---- pieces shared with the kernel-mode model (wan/quant_wanx_hip.py)
+    def embed(self, x, t, context, seq_len):
+        dev = self.patch_embedding.weight.device
+        x = [self.patch_embedding(u.unsqueeze(0).to(self.patch_embedding.weight.dtype)) for u in x]
+        grid_sizes = [tuple(u.shape[2:]) for u in x]
+        x = [u.flatten(2).transpose(1, 2) for u in x]
+        seq_lens = [u.size(1) for u in x]
+        assert max(seq_lens) <= seq_len
+        x = torch.cat([torch.cat([u, u.new_zeros(1, seq_len - u.size(1), u.size(2))], dim=1) for u in x])
+        with torch.autocast("cuda", enabled=False):
+            e = self.time_embedding(sinusoidal_embedding_1d(self.freq_dim, t.to(dev)).float())
+            e0 = self.time_projection(e).unflatten(1, (6, self.dim))
+        context = self.text_embedding(torch.stack([
+            torch.cat([u, u.new_zeros(self.text_len - u.size(0), u.size(1))]) for u in context]).to(dev))
+        return x, e, e0, context, seq_lens, grid_sizes
+
+    def unpatchify(self, x, grid_sizes):
+        c, out = self.out_dim, []
+        for u, g in zip(x, grid_sizes):
+            u = u[: math.prod(g)].view(*g, *self.patch_size, c)
+            u = torch.einsum("fhwpqrc->cfphqwr", u)
+            out.append(u.reshape(c, *[i * j for i, j in zip(g, self.patch_size)]))
+        return out
+
+    def forward(self, x, t, context, seq_len):
+        x, e, e0, context, seq_lens, grid_sizes = self.embed(x, t, context, seq_len)
+        x = x.float()
+        for block in self.blocks:
+            x = block(x, e0, seq_lens, grid_sizes, self.freqs, context, None)
+        x = self.head(x, e)
+        return [u.float() for u in self.unpatchify(x, grid_sizes)]
+
+    def init_weights(self):
+        """Xavier-uniform Linear / zero bias, N(0, .02) for the text/time MLPs (reference model.py:658-680);
+        the head is zero there -- callers that need a non-trivial synthetic model re-draw it."""
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+        nn.init.xavier_uniform_(self.patch_embedding.weight.flatten(1))
+        for seq in (self.text_embedding, self.time_embedding):
+            for m in seq.modules():
+                if isinstance(m, nn.Linear):
+                    nn.init.normal_(m.weight, std=0.02)
+        nn.init.zeros_(self.head.head.weight)
+
+    @classmethod
+    def from_pretrained(cls, checkpoint_dir, **overrides):
+        """Load a Wan2.1 checkpoint directory: config.json + *.safetensors (diffusers layout)."""
+        from safetensors.torch import load_file
+
+        cfg = json.load(open(os.path.join(checkpoint_dir, "config.json")))
+        keys = ("model_type", "patch_size", "text_len", "in_dim", "dim", "ffn_dim", "freq_dim", "text_dim", "out_dim",
+                "num_heads", "num_layers", "window_size", "qk_norm", "cross_attn_norm", "eps")
+        kw = {k: cfg[k] for k in keys if k in cfg}
+        kw.update(overrides)
+        model = cls(**kw)
+        sd = {}
+        for f in sorted(os.listdir(checkpoint_dir)):
+            if f.endswith(".safetensors"):
+                sd.update(load_file(os.path.join(checkpoint_dir, f)))
+        model.load_state_dict(sd, strict=True)
+        return model

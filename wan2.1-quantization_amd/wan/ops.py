@@ -1,0 +1,55 @@
+"""Functional wrappers over libwanq_hip for the DiT block (no module state)."""
+import math
+
+import torch
+
+from viditq_extension import _C, fused, qgemm  # noqa: F401
+
+
+def rmsnorm_rope_(x, weight, rope, head_dim, rows_per_batch=None, eps=1e-6, out=None):
+    """In place by default: x[rows, C] <- RMSNorm_C(x) * weight, then rotary per head from `rope`
+    (fp32 [positions, head_dim/2, 2]).  Either of weight / rope may be None."""
+    _C.check_gpu("x", x)
+    _C.check_contig("x", x)
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    if weight is not None:
+        _C.check_dtype("weight", weight, torch.float32)
+        _C.check_shape("weight", weight, cols)
+    positions = 0
+    if rope is not None:
+        _C.check_dtype("rope", rope, torch.float32)
+        _C.check_contig("rope", rope)
+        if rope.dim() != 3 or rope.shape[1] != head_dim // 2 or rope.shape[2] != 2:
+            raise RuntimeError(f"rope must have shape (positions, {head_dim // 2}, 2)")
+        positions = rope.shape[0]
+    out = x if out is None else out
+    with torch.cuda.device(x.device):
+        _C.call("wanq_rmsnorm_rope", _C.ptr(x), _C.dt(x), _C.ptr(weight), _C.ptr(rope), _C.ptr(out), _C.dt(out), rows, cols,
+                head_dim, rows_per_batch or rows, positions, float(eps), _C.stream())
+    return out
+
+
+def rope_table(freqs, grid, device):
+    """(cos, sin) table fp32 [f*h*w, d/2, 2] for one (f,h,w) grid from the model's complex freqs [1024, d/2]
+    -- the `freqs_i` of rope_apply (wan/modules/model.py:56-61), built once per grid in float64."""
+    f, h, w = grid
+    c = freqs.shape[1]
+    parts = freqs.split([c - 2 * (c // 3), c // 3, c // 3], dim=1)
+    fi = torch.cat([parts[0][:f].view(f, 1, 1, -1).expand(f, h, w, -1),
+                    parts[1][:h].view(1, h, 1, -1).expand(f, h, w, -1),
+                    parts[2][:w].view(1, 1, w, -1).expand(f, h, w, -1)], dim=-1).reshape(f * h * w, c)
+    return torch.view_as_real(fi).to(torch.float32).contiguous().to(device)
+
+
+def attention(q, k, v, num_heads, k_len=None):
+    """softmax(q k^T / sqrt(d)) v for one sample.  q [Lq, C], k/v [Lk, C] (bf16/fp16) -> [Lq, C].
+    k_len masks key padding (flash_attention(..., k_lens) in wan/modules/attention.py:78-80)."""
+    Lq, C = q.shape
+    d = C // num_heads
+    if k_len is not None and k_len < k.shape[0]:
+        k, v = k[:k_len], v[:k_len]
+    qh = q.view(1, Lq, num_heads, d).transpose(1, 2)
+    kh = k.view(1, k.shape[0], num_heads, d).transpose(1, 2)
+    vh = v.view(1, v.shape[0], num_heads, d).transpose(1, 2)
+    o = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh, scale=1.0 / math.sqrt(d))
+    return o.transpose(1, 2).reshape(Lq, C)
