@@ -38,11 +38,13 @@ class HipLinearW8A8(nn.Module):
         """delta, zero_point of StaticQuantizer.init_quant_params (base_quantizer.py:70-90); the row statistics
         come from the HIP reduction, the [N]-sized arithmetic is plain fp32 (IEEE: bit-identical to CPU torch)."""
         lo, hi, am = fused.row_minmax(w)
+        # NB: on the GPU torch evaluates `tensor / python_scalar` as a multiply by the reciprocal (1 ulp off the
+        # IEEE quotient now and then); the golden vectors are IEEE divisions, so divide by a TENSOR.
         if sym:
-            return am / float(2 ** (n_bits - 1) - 1), torch.zeros_like(am)
+            return am / torch.full_like(am, float(2 ** (n_bits - 1) - 1)), torch.zeros_like(am)
         n_levels = 2 ** n_bits
         hi, lo = hi.clamp_min(0.0), lo.clamp_max(0.0)
-        delta = (hi - lo) / float(n_levels - 1)
+        delta = (hi - lo) / torch.full_like(hi, float(n_levels - 1))
         return delta, torch.round(lo / delta) + n_levels / 2
 
     @classmethod
