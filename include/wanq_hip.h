@@ -127,6 +127,16 @@ int wanq_rmsnorm_rope(const void* x, int x_dtype, const float* weight, const flo
                       int out_dtype, int64_t rows, int cols, int head_dim, int64_t rows_per_batch,
                       int64_t positions, float eps, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Flash-attention forward, non-causal:  o[q,h,:] = softmax_k(q[q,h,:].k[k,h,:] * scale) v[k,h,:] over the
+ * first Lk keys.  Token-major tensors [tokens, heads*head_dim] with a token stride in ELEMENTS (so q/k/v may
+ * be column slices of one packed buffer).  dtype: WANQ_BF16; head_dim: 128.  fp32 online softmax, bf16 MFMA.
+ * Replaces flash_attention(q, k, v, k_lens) (ViDiT-Q/examples/Wan2.1/wan/modules/attention.py:24-130, which
+ * calls the external flash_attn library) for batch size 1. */
+int wanq_attention_fwd(const void* q, const void* k, const void* v, void* o, int dtype, int64_t Lq,
+                       int64_t Lk, int heads, int head_dim, int64_t q_stride, int64_t k_stride,
+                       int64_t v_stride, int64_t o_stride, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

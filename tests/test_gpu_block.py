@@ -108,3 +108,36 @@ def test_weight_codes_and_params_match_oracle():
     assert torch.equal(hl.scale_weight.cpu(), delta.view(-1)) and torch.equal(hl.zp_weight.cpu(), zp.view(-1))
     deq = (hl.weight.float().cpu() + zp) * delta
     assert torch.equal(deq, wr.static_fake_quant(w))
+
+
+@pytest.mark.parametrize("Lq,Lk,H,klen", [(32, 64, 1, None), (300, 300, 2, None), (256, 64, 3, None), (100, 512, 2, None),
+                                           (1000, 777, 2, None), (515, 640, 12, 601), (2050, 2050, 4, None)])
+def test_flash_attention_vs_fp32_softmax(Lq, Lk, H, klen):
+    """No fixture of the reference pins attention (flash_attn is an external library): the pin is the fp32
+    definition softmax(QK^T/sqrt(d))V on the same bf16 inputs.  Tolerance: P is rounded to bf16 before PV
+    (as flash-attn does) -> abs error <= 2^-8 * max|v| on outputs of magnitude <= max|v|."""
+    from wan import ops
+
+    d = 128
+    g = torch.Generator().manual_seed(Lq * 31 + Lk)
+    q = (torch.randn(Lq, H * d, generator=g) * 1.5).to(torch.bfloat16)
+    k = (torch.randn(Lk, H * d, generator=g) * 1.5).to(torch.bfloat16)
+    v = torch.randn(Lk, H * d, generator=g).to(torch.bfloat16)
+    if Lk > 70:  # one dominant key for some queries: exercises the running-max rescale
+        k[69] *= 4.0
+    ref = wr.attention(q.float().view(Lq, H, d), k.float().view(Lk, H, d), v.float().view(Lk, H, d), klen).reshape(Lq, H * d)
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), H, klen)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err < 3e-2, err
+    assert rel_err(out.float().cpu(), ref) < 1e-2
+
+
+def test_flash_attention_strided_views_of_packed_qkv():
+    from wan import ops
+
+    L, H, d = 200, 2, 128
+    qkv = torch.randn(L, 3 * H * d, generator=torch.Generator().manual_seed(8)).to(torch.bfloat16).to(DEV)
+    q, k, v = qkv[:, : H * d], qkv[:, H * d: 2 * H * d], qkv[:, 2 * H * d:]
+    out = ops.attention(q, k, v, H)
+    ref = ops.attention(q.contiguous(), k.contiguous(), v.contiguous(), H)
+    assert torch.equal(out, ref)

@@ -1,0 +1,237 @@
+// Flash-attention forward for gfx950 (bf16 MFMA 32x32x16), head_dim 128, non-causal, key-length masking.
+//
+//   O[q, h, :] = softmax_k( Q[q,h,:] . K[k,h,:] / sqrt(d) ) V[k,h,:]
+//
+// Layout: Q/K/V/O are token-major [tokens, heads*128] bf16 (exactly what the q/k/v GEMMs write and what the
+// o-projection's quantiser reads), so no head transposes exist anywhere.
+//
+// Structure: one workgroup = 8 waves = 256 queries of one head; every wave owns 32 queries for the whole
+// kernel.  Per 64-key tile:
+//   S^T = K . Q^T      A operand = K rows from LDS (ds_read_b128), B operand = Q held in registers;
+//                      the 32x32 accumulator then has ONE query per lane (lane&31) and 16 keys in registers,
+//                      so the online-softmax row statistics are lane-local (one cross-lane max with lane^32);
+//   O^T += V^T . P^T   B operand = the S^T accumulator itself, converted to bf16 in place (the accumulator's
+//                      register->key permutation 8(j>>2)+4h+(j&3) is matched by the order in which the A
+//                      operand V^T is gathered with ds_read_b64_tr_b16), so P never touches LDS.
+// K and V tiles are double-buffered in LDS (64 KiB), fetched global->registers one tile ahead and written
+// to LDS in the middle of the iteration (one barrier per tile).  LDS rows are 256 B with the 16-B chunk
+// index XORed by ((row&3)<<2 | (row>>2)&3): conflict-free for the b128 row reads of K, the transposed reads
+// of V and the staging writes.
+#include "wanq_common.h"
+
+namespace wanq {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct AttnParams {
+  const uint16_t* q;
+  const uint16_t* k;
+  const uint16_t* v;
+  uint16_t* o;
+  int64_t q_stride, k_stride, v_stride, o_stride;  // elements between consecutive tokens
+  int Lq, Lk, H;
+  float c;  // softmax scale * log2(e)
+};
+
+constexpr int AT_D = 128, AT_QW = 32, AT_NW = 8, AT_QB = AT_QW * AT_NW, AT_KB = 64;
+constexpr int AT_TILE = AT_KB * AT_D * 2;  // 16 KiB per K or V tile
+constexpr int AT_STAGE = 2 * AT_TILE;
+
+__device__ __forceinline__ int at_off(int row, int ch) {
+  return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+}
+
+__global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int head = blockIdx.y;
+  const int q0 = blockIdx.x * AT_QB + wave * AT_QW;
+  const int nt = (p.Lk + AT_KB - 1) / AT_KB;
+  const float c = p.c;
+
+  // ---- Q fragments: query (q0+fr), d = 16 s + 8 fh + [0,8)
+  bf16x8 qf[8];
+  {
+    int qr = q0 + fr;
+    if (qr >= p.Lq) qr = p.Lq - 1;
+    const uint16_t* qp = p.q + (int64_t)qr * p.q_stride + head * AT_D + 8 * fh;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+  }
+
+  // ---- staging: thread handles 16-B chunks `tid` and `tid+512` of the 64x16-chunk K tile and V tile
+  const int st_row0 = tid >> 4, st_ch = tid & 15;  // second chunk: row + 32
+  const uint16_t* kbase = p.k + head * AT_D + st_ch * 8;
+  const uint16_t* vbase = p.v + head * AT_D + st_ch * 8;
+  // (explicit scalars + macros: arrays captured by a lambda end up in scratch memory)
+  uint4 rk0, rk1, rv0, rv1;
+  const int st_off0 = at_off(st_row0, st_ch), st_off1 = at_off(st_row0 + 32, st_ch);
+#define AT_GLOAD(j)                                                                   \
+  do {                                                                                \
+    int kr0 = (j) * AT_KB + st_row0, kr1 = kr0 + 32;                                  \
+    kr0 = kr0 < p.Lk ? kr0 : p.Lk - 1;                                                \
+    kr1 = kr1 < p.Lk ? kr1 : p.Lk - 1;                                                \
+    rk0 = *reinterpret_cast<const uint4*>(kbase + (int64_t)kr0 * p.k_stride);         \
+    rk1 = *reinterpret_cast<const uint4*>(kbase + (int64_t)kr1 * p.k_stride);         \
+    rv0 = *reinterpret_cast<const uint4*>(vbase + (int64_t)kr0 * p.v_stride);         \
+    rv1 = *reinterpret_cast<const uint4*>(vbase + (int64_t)kr1 * p.v_stride);         \
+  } while (0)
+#define AT_LSTORE(stage)                                                              \
+  do {                                                                                \
+    char* sK_ = smem + (stage) * AT_STAGE;                                            \
+    *reinterpret_cast<uint4*>(sK_ + st_off0) = rk0;                                   \
+    *reinterpret_cast<uint4*>(sK_ + st_off1) = rk1;                                   \
+    *reinterpret_cast<uint4*>(sK_ + AT_TILE + st_off0) = rv0;                         \
+    *reinterpret_cast<uint4*>(sK_ + AT_TILE + st_off1) = rv1;                         \
+  } while (0)
+
+  // ---- transposed-read lane constants for V^T: 16-lane group g, lane 4q+p inside it
+  const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int v_row = 4 * (tg >> 1) + tq;                 // + 16 ks (+8 for the second read)
+  const int v_ch = 2 * (tg & 1) + (tp >> 1);            // + 4 db
+  const int v_half = 8 * (tp & 1);
+
+  f32x16 o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  AT_GLOAD(0);
+  AT_LSTORE(0);
+  if (nt > 1) AT_GLOAD(1);
+  __syncthreads();
+
+  for (int j = 0; j < nt; ++j) {
+    const int cur = j & 1;
+    const char* sK = smem + cur * AT_STAGE;
+    const char* sV = sK + AT_TILE;
+
+    // ---------------- S^T = K . Q^T  (two 32-key blocks)
+    f32x16 s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(sK + at_off(fr, 2 * s + fh));
+      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(sK + at_off(32 + fr, 2 * s + fh));
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s], s1, 0, 0, 0);
+    }
+    if (j == nt - 1 && (p.Lk & (AT_KB - 1))) {  // ragged last tile: keys >= Lk get -inf
+      const int kb = j * AT_KB + 4 * fh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb + (r & 3) + 8 * (r >> 2);
+        if (key >= p.Lk) s0[r] = -INFINITY;
+        if (key + 32 >= p.Lk) s1[r] = -INFINITY;
+      }
+    }
+
+    // ---------------- online softmax, one query per lane (its 64 scores live in lanes l and l^32)
+    float mx = s0[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+    m_run = m_new;
+    const float mc = m_new * c;
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc));
+      s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc));
+      ls += s0[r] + s1[r];
+    }
+    l_run = l_run * alpha + ls;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    bf16x8 pf[4];  // key slice ks = 2*block + t: registers 8t..8t+7 of that block's accumulator
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      pf[0][e] = (__bf16)s0[e];
+      pf[1][e] = (__bf16)s0[8 + e];
+      pf[2][e] = (__bf16)s1[e];
+      pf[3][e] = (__bf16)s1[8 + e];
+    }
+
+    // ---------------- next tile: registers -> other LDS stage, then fetch the tile after it
+    if (j + 1 < nt) {
+      AT_LSTORE(cur ^ 1);
+      if (j + 2 < nt) AT_GLOAD(j + 2);
+    }
+
+    // ---------------- O^T += V^T . P^T
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const char* a0 = sV + at_off(16 * ks + v_row, 4 * db + v_ch) + v_half;
+        const char* a1 = sV + at_off(16 * ks + 8 + v_row, 4 * db + v_ch) + v_half;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a1);
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[ks], o[db], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: O[q, d] = O^T[d, q] / l ; lane holds d = 32 db + (r&3) + 8 (r>>2) + 4 fh of query fr
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qr = q0 + fr;
+  if (qr < p.Lq) {
+    uint16_t* op = p.o + (int64_t)qr * p.o_stride + head * AT_D + 4 * fh;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x4 b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = (__bf16)(o[db][4 * g + e] * inv);
+        *reinterpret_cast<bf16x4*>(op + 32 * db + 8 * g) = b;
+      }
+  }
+}
+
+}  // namespace wanq
+
+using namespace wanq;
+
+extern "C" int wanq_attention_fwd(const void* q, const void* k, const void* v, void* o, int dtype, int64_t Lq,
+                                  int64_t Lk, int heads, int head_dim, int64_t q_stride, int64_t k_stride,
+                                  int64_t v_stride, int64_t o_stride, float scale, void* stream) {
+  WANQ_REQUIRE(q && k && v && o, WANQ_E_ARG, "wanq_attention_fwd: NULL pointer");
+  WANQ_REQUIRE(dtype == WANQ_BF16, WANQ_E_ARG, "wanq_attention_fwd: only bf16 is implemented (dtype code %d)", dtype);
+  WANQ_REQUIRE(head_dim == AT_D, WANQ_E_SHAPE, "wanq_attention_fwd: head_dim=%d, only 128 is implemented", head_dim);
+  WANQ_REQUIRE(heads >= 1 && heads <= 65535, WANQ_E_SHAPE, "wanq_attention_fwd: heads=%d out of range", heads);
+  WANQ_REQUIRE(Lq >= 0 && Lk >= 1 && Lq < (1ll << 30) && Lk < (1ll << 30), WANQ_E_SHAPE, "wanq_attention_fwd: bad lengths");
+  const int64_t need = (int64_t)heads * head_dim;
+  WANQ_REQUIRE(q_stride >= need && k_stride >= need && v_stride >= need && o_stride >= need, WANQ_E_SHAPE,
+               "wanq_attention_fwd: token stride smaller than heads*head_dim");
+  WANQ_REQUIRE((q_stride | k_stride | v_stride | o_stride) % 8 == 0, WANQ_E_SHAPE, "wanq_attention_fwd: strides must be multiples of 8 elements");
+  if (Lq == 0) return WANQ_OK;
+  AttnParams p{(const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (uint16_t*)o, q_stride, k_stride, v_stride, o_stride,
+               (int)Lq, (int)Lk, heads, scale * 1.4426950408889634f};
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_STAGE);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)((Lq + AT_QB - 1) / AT_QB), (unsigned)heads);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(512), 2 * AT_STAGE, (hipStream_t)stream, p);
+  return check_launch("wanq_attention_fwd");
+}

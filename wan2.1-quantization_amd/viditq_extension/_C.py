@@ -35,6 +35,7 @@ PROTOTYPES = {
     "wanq_row_minmax": [_vp, _i, _vp, _vp, _vp, _i64, _i, _vp],
     "wanq_weight_quant": [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _i64, _i, _vp],
     "wanq_rmsnorm_rope": [_vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _i64, _i64, _f, _vp],
+    "wanq_attention_fwd": [_vp, _vp, _vp, _vp, _i, _i64, _i64, _i, _i, _i64, _i64, _i64, _i64, _f, _vp],
 }
 for _name, _args in PROTOTYPES.items():
     _fn = getattr(lib, _name)  # AttributeError here = header and library out of sync

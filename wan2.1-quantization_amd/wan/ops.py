@@ -41,9 +41,30 @@ def rope_table(freqs, grid, device):
     return torch.view_as_real(fi).to(torch.float32).contiguous().to(device)
 
 
-def attention(q, k, v, num_heads, k_len=None):
-    """softmax(q k^T / sqrt(d)) v for one sample.  q [Lq, C], k/v [Lk, C] (bf16/fp16) -> [Lq, C].
-    k_len masks key padding (flash_attention(..., k_lens) in wan/modules/attention.py:78-80)."""
+def attention(q, k, v, num_heads, k_len=None, out=None):
+    """softmax(q k^T / sqrt(d)) v for one sample on the HIP flash-attention kernel (csrc/attention.hip).
+    q [Lq, C], k/v [Lk, C] bf16, token-major (row stride may exceed C: column slices of a packed buffer are
+    fine) -> [Lq, C].  k_len masks key padding (flash_attention(..., k_lens), wan/modules/attention.py:78-80)."""
+    Lq, C = q.shape
+    d = C // num_heads
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        _C.check_gpu(n, t)
+        _C.check_dtype(n, t, torch.bfloat16)
+        if t.dim() != 2 or t.shape[1] != C or t.stride(1) != 1:
+            raise RuntimeError(f"Tensor {n} must be [tokens, {C}] with unit column stride")
+    if k.shape[0] != v.shape[0]:
+        raise RuntimeError("k and v must have the same number of tokens")
+    Lk = k.shape[0] if k_len is None else min(int(k_len), k.shape[0])
+    if out is None:
+        out = torch.empty(Lq, C, dtype=q.dtype, device=q.device)
+    with torch.cuda.device(q.device):
+        _C.call("wanq_attention_fwd", _C.ptr(q), _C.ptr(k), _C.ptr(v), _C.ptr(out), _C.dt(q), Lq, Lk, num_heads, d,
+                q.stride(0), k.stride(0), v.stride(0), out.stride(0), 1.0 / math.sqrt(d), _C.stream())
+    return out
+
+
+def attention_sdpa(q, k, v, num_heads, k_len=None):
+    """The same contraction through torch SDPA -- kept ONLY as a timing reference for tools/microbench.py."""
     Lq, C = q.shape
     d = C // num_heads
     if k_len is not None and k_len < k.shape[0]:
