@@ -14,6 +14,7 @@
 // ds_read_b128 fragment reads and ds_write_b128 staging writes are both bank-conflict free.
 // Workgroup ids are remapped so that each XCD's L2 sees a compact (8 m-tiles x n) panel.
 #include "wanq_common.h"
+#include <stdlib.h>
 
 namespace wanq {
 
@@ -39,6 +40,7 @@ struct GemmParams {
 constexpr int BM = 128, BN = 128, BK = 128;
 constexpr int STAGE_BYTES = (BM + BN) * BK;  // 32 KiB
 constexpr int GROUP_M = 8;
+static bool g_force_v1 = false;  // test hook: WANQ_GEMM_V1=1 in the environment
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -254,15 +256,271 @@ __global__ __launch_bounds__(256, 2) void gemm_w8a8_kernel(const GemmParams p) {
   }
 }
 
+// =====================================================================================================
+// v2 (large M): persistent kernel, 256(M) x 256(N) tile, 8 waves as 2(M) x 4(N), each wave 128 tokens x 64
+// channels = 4 x 2 MFMA tiles (6 ds_read_b128 per 8 MFMAs).
+//  * Both operands go global -> LDS directly (global_load_lds_dwordx4, 16 B per lane, one 1-KiB wave
+//    instruction = 8 rows x 128 B); the LDS image stays lane-linear and the bank swizzle is applied on the
+//    per-lane SOURCE address (and on the fragment reads).
+//  * Two 64-KiB stages: the loads of K-tile t+1 are issued right after the barrier that publishes tile t and
+//    fly under its 32 MFMAs per wave (one barrier per K tile); inside a K tile the fragments of k-step s+1 are
+//    read while the MFMAs of k-step s issue (register double buffer).
+//  * One workgroup per CU walks its tiles: the first K-tile of the NEXT output tile is requested before the
+//    epilogue of the current one, and the wait that publishes it is a COUNTED s_waitcnt vmcnt(#epilogue
+//    stores), so the epilogue's stores drain to HBM underneath the next tile's main loop instead of stalling
+//    every CU at the same time.
+// Used when M >= 512 and K % 128 == 0; everything else takes the v1 kernel.
+constexpr int B2M = 256, B2N = 256, B2K = 128;
+constexpr int B2_STAGE = (B2M + B2N) * B2K;  // 64 KiB
+
 template <int OUT>
-static int launch_gemm(const GemmParams& p, hipStream_t st) {
+__global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef __attribute__((address_space(1))) const void glb_void;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int K = p.K;
+  const int nk = K / B2K;
+  const int ntiles = p.mt * p.nt;
+
+  // tile id -> (m0, n0): XCD-contiguous ids (bijective remap; gridDim.x % 8 == 0 so a workgroup's tiles all
+  // sit in its own XCD's range), then groups of GROUP_M m-tiles
+  auto tile_origin = [&](int t, int& m0, int& n0) {
+    const int xq = ntiles >> 3, xr = ntiles & 7, xcd = t & 7;
+    const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (t >> 3);
+    const int per_group = GROUP_M * p.nt;
+    const int group = wg / per_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = (p.mt - first_m < GROUP_M) ? (p.mt - first_m) : GROUP_M;
+    const int in_g = wg - group * per_group;
+    m0 = (first_m + in_g % gsz) * B2M;
+    n0 = (in_g / gsz) * B2N;
+  };
+
+  // LDS-DMA: instruction g of this wave fills rows 8*(wave+8g) .. +7 of a stage (1 KiB, lane-linear)
+  const int drow = wave * 8 + (lane >> 3);  // + 64 g
+  uint32_t srcx[4], srcw[4];  // byte offsets from p.a / p.w (M*K and N*K < 4 GiB is checked on the host)
+  auto set_sources = [&](int m0, int n0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int row = drow + 64 * g;
+      const int lc = (lane & 7) ^ ((row >> 1) & 7);  // logical chunk that belongs at this physical slot
+      const int gm = (m0 + row < p.M) ? (m0 + row) : (p.M - 1);
+      const int gn = (n0 + row < p.N) ? (n0 + row) : (p.N - 1);
+      srcx[g] = (uint32_t)gm * (uint32_t)K + lc * 16;
+      srcw[g] = (uint32_t)gn * (uint32_t)K + lc * 16;
+    }
+  };
+#define B2_ISSUE(kt, stage)                                                                              \
+  do {                                                                                                   \
+    char* sx_ = smem + (stage) * B2_STAGE + wave * 1024;                                                 \
+    const int8_t* ak_ = p.a + (kt) * B2K;                                                                \
+    const int8_t* wk_ = p.w + (kt) * B2K;                                                                \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                      \
+      __builtin_amdgcn_global_load_lds((glb_void*)(ak_ + srcx[g]), (lds_void*)(sx_ + g * 8192), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((glb_void*)(wk_ + srcw[g]), (lds_void*)(sx_ + B2M * B2K + g * 8192), 16, 0, 0); \
+    }                                                                                                    \
+  } while (0)
+
+  // fragment reads: W rows wn*64 + i*32 + fr, X rows wm*128 + j*32 + fr.  The row swizzle (row>>1)&7 equals
+  // (fr>>1)&7 for every i / j, so one chunk offset per k-step serves all six reads (i, j become immediates).
+  const int fsw = (fr >> 1) & 7;
+  int ck[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) ck[ks] = ((2 * ks + fh) ^ fsw) << 4;
+  const int rowx = (wm * 128 + fr) * B2K, roww = B2M * B2K + (wn * 64 + fr) * B2K;
+
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  int m0, n0;
+  tile_origin(tile, m0, n0);
+  set_sources(m0, n0);
+  B2_ISSUE(0, 0);
+  int pending_stores = 0;  // epilogue store instructions issued after the loads now in flight
+
+  for (;;) {
+    v16i acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+    for (int kt = 0; kt < nk; ++kt) {
+      // publish K-tile kt: my LDS-DMA for it has landed (everything older than the last `pending_stores`
+      // vector-memory ops), then the barrier makes that true for every wave and also says every wave has
+      // finished reading the other stage.
+      if (pending_stores == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      pending_stores = 0;
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nk) B2_ISSUE(kt + 1, (kt + 1) & 1);
+      const char* st = smem + (kt & 1) * B2_STAGE;
+      v4i wf[2][2], xf[2][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wf[0][i] = *reinterpret_cast<const v4i*>(st + roww + ck[0] + i * 32 * B2K);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xf[0][j] = *reinterpret_cast<const v4i*>(st + rowx + ck[0] + j * 32 * B2K);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int cb = ks & 1, nb = cb ^ 1;
+        if (ks < 3) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) wf[nb][i] = *reinterpret_cast<const v4i*>(st + roww + ck[ks + 1] + i * 32 * B2K);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xf[nb][j] = *reinterpret_cast<const v4i*>(st + rowx + ck[ks + 1] + j * 32 * B2K);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads of k-step s+1 AHEAD of the MFMAs of k-step s
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[cb][i], xf[cb][j], acc[i][j], 0, 0, 0);
+      }
+    }
+
+    // ---- all waves are done with LDS.  Epilogue, in this order:
+    //   1. ONE round trip: this tile's 256 per-channel values (sW, zp*sW, bias, gate) -> LDS (stage 1, free until
+    //      the next tile's second K-tile), per-token sA / sumA -> registers;
+    //   2. request the next tile's first K-tile (stage 0) so that it flies under the store loop;
+    //   3. store loop: reads LDS only (no vector-memory loads, hence no vmcnt waits: stores just queue up).
+    //      With a residual the loop must also LOAD; then step 2 moves behind the loop (hipcc would otherwise
+    //      wait vmcnt(0) on every residual load while LDS-DMA is in flight).
+    const int cur_m0 = m0, cur_n0 = n0;
+    const int next = tile + gridDim.x;
+    const bool has_res = (p.epi & WANQ_EPI_GATE_RES) != 0;
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    float* chan = reinterpret_cast<float*>(smem + B2_STAGE);  // [4][256]: sW, zp*sW, bias, gate
+    float sa_m[4] = {1.f, 1.f, 1.f, 1.f}, asum_m[4] = {0.f, 0.f, 0.f, 0.f};
+    int mrow[4], mcl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mrow[j] = cur_m0 + wm * 128 + j * 32 + fr;
+      mcl[j] = mrow[j] < p.M ? mrow[j] : p.M - 1;
+    }
+    if (OUT != WANQ_I32) {  // one uniform branch per dtype so that the four loads of a kind issue together
+      if (p.tok_dtype == WANQ_F32) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sa_m[j] = static_cast<const float*>(p.sa)[mcl[j]];
+        if (p.zp) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) asum_m[j] = static_cast<const float*>(p.asum)[mcl[j]];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sa_m[j] = __half2float(static_cast<const __half*>(p.sa)[mcl[j]]);
+        if (p.zp) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) asum_m[j] = __half2float(static_cast<const __half*>(p.asum)[mcl[j]]);
+        }
+      }
+    }
+    if (OUT != WANQ_I32) {
+      if (tid < 256) {
+        const int nc = (cur_n0 + tid < p.N) ? cur_n0 + tid : p.N - 1;
+        const float swv = vec_load(p.sw, p.ch_dtype, nc);
+        float zv = 0.f;
+        if (p.zp) zv = (p.zp_dtype == WANQ_I16) ? (float)static_cast<const short*>(p.zp)[nc] : static_cast<const float*>(p.zp)[nc];
+        chan[tid] = swv;
+        chan[256 + tid] = zv * swv;
+        chan[512 + tid] = p.bias ? vec_load(p.bias, p.ch_dtype, nc) : 0.f;
+        chan[768 + tid] = has_res ? p.gate[nc] : 0.f;
+      }
+      __syncthreads();
+    }
+    if (next < ntiles) {
+      tile_origin(next, m0, n0);
+      set_sources(m0, n0);
+      if (!has_res) B2_ISSUE(0, 0);
+    }
+    const bool full_tile = (cur_m0 + B2M <= p.M) && (cur_n0 + B2N <= p.N);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = wn * 64 + i * 32 + 8 * g + 4 * fh;  // channel inside the tile
+        const int n = cur_n0 + nl;
+        const bool n_ok = n < p.N;
+        float4 sw4 = make_float4(1.f, 1.f, 1.f, 1.f), zs4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = zs4, g4 = zs4;
+        if (OUT != WANQ_I32) {
+          sw4 = *reinterpret_cast<const float4*>(chan + nl);
+          zs4 = *reinterpret_cast<const float4*>(chan + 256 + nl);
+          b4 = *reinterpret_cast<const float4*>(chan + 512 + nl);
+          if (has_res) g4 = *reinterpret_cast<const float4*>(chan + 768 + nl);
+        }
+        const float swa[4] = {sw4.x, sw4.y, sw4.z, sw4.w}, zsa[4] = {zs4.x, zs4.y, zs4.z, zs4.w};
+        const float ba[4] = {b4.x, b4.y, b4.z, b4.w}, ga[4] = {g4.x, g4.y, g4.z, g4.w};
+        float r4[4][4];
+        if (OUT != WANQ_I32 && has_res) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            OutIo<OUT == WANQ_I32 ? WANQ_F32 : OUT>::load4(p.residual, (int64_t)mcl[j] * p.N + (n_ok ? n : 0), r4[j]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (!full_tile && (mrow[j] >= p.M || !n_ok)) continue;
+          const int64_t o = (int64_t)mrow[j] * p.N + n;
+          if (OUT == WANQ_I32) {
+            *reinterpret_cast<int4*>(static_cast<int*>(p.out) + o) =
+                make_int4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+          } else {
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)  // acc*sA*sW + (sumA*(zp*sW) + bias)
+              y[e] = fmaf((float)acc[i][j][4 * g + e] * sa_m[j], swa[e], fmaf(asum_m[j], zsa[e], ba[e]));
+            if (p.epi & WANQ_EPI_GELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_f32(y[e]);
+            }
+            if (has_res) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) y[e] = fmaf(y[e], ga[e], r4[j][e]);
+            }
+            OutIo<OUT == WANQ_I32 ? WANQ_F32 : OUT>::store4(p.out, o, y);
+          }
+        }
+      }
+    }
+    if (next >= ntiles) break;
+    // A full tile issues exactly 32 store instructions per wave after the LDS-DMA above; a ragged tile may
+    // issue fewer (whole-wave skips), so it falls back to a full drain.
+    if (has_res) {
+      B2_ISSUE(0, 0);  // behind the stores: the first barrier of the next tile drains them (vmcnt(0))
+      pending_stores = 0;
+    } else {
+      pending_stores = full_tile ? 32 : 0;
+    }
+    tile = next;
+  }
+#undef B2_ISSUE
+}
+
+template <int OUT>
+static int launch_gemm(GemmParams p, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w8a8_kernel<OUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        2 * STAGE_BYTES);
+                              2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w8a8_big_kernel<OUT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * B2_STAGE);
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_w8a8_kernel<OUT>, dim3((unsigned)(p.mt * p.nt)), dim3(256), 2 * STAGE_BYTES, st, p);
+  if (p.M >= 512 && p.K % B2K == 0 && !g_force_v1 && (int64_t)p.M * p.K < (1ll << 32) && (int64_t)p.N * p.K < (1ll << 32)) {
+    p.mt = (p.M + B2M - 1) / B2M;
+    p.nt = (p.N + B2N - 1) / B2N;
+    const int tiles = p.mt * p.nt;
+    const int grid = tiles < 256 ? ((tiles + 7) & ~7) : 256;  // one workgroup per CU; % 8 == 0 for the XCD ranges
+    hipLaunchKernelGGL(gemm_w8a8_big_kernel<OUT>, dim3((unsigned)grid), dim3(512), 2 * B2_STAGE, st, p);
+  } else {
+    hipLaunchKernelGGL(gemm_w8a8_kernel<OUT>, dim3((unsigned)(p.mt * p.nt)), dim3(256), 2 * STAGE_BYTES, st, p);
+  }
   return check_launch("wanq_gemm_w8a8");
 }
 
@@ -292,6 +550,10 @@ extern "C" int wanq_gemm_w8a8(const int8_t* a, const int8_t* w, void* out, int o
   }
   WANQ_REQUIRE((epi_flags & ~(WANQ_EPI_GELU | WANQ_EPI_GATE_RES)) == 0, WANQ_E_ARG, "wanq_gemm_w8a8: unknown epilogue flag");
   if (M == 0) return WANQ_OK;
+  {
+    static const bool v1 = [] { const char* e = getenv("WANQ_GEMM_V1"); return e && e[0] == '1'; }();
+    g_force_v1 = v1;
+  }
   GemmParams p{};
   p.a = a; p.w = w; p.out = out; p.sa = sa; p.asum = asum; p.sw = sw; p.bias = bias; p.zp = zp; p.gate = gate;
   p.residual = residual; p.tok_dtype = tok_dtype; p.ch_dtype = ch_dtype; p.zp_dtype = zp_dtype; p.epi = epi_flags;
