@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--guide", type=float, default=5.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quality", action="store_true")
+    ap.add_argument("--no-cfg-parallel", action="store_true", help="pure Ulysses over all GPUs (needs heads %% N == 0)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -137,16 +138,19 @@ def main():
 
     from viditq_extension import qgemm
     from wan.configs import SIZE_CONFIGS, WAN_CONFIGS, latent_shape, seq_len_for
+    from wan.distributed.parallel import ParallelPlan
     from wan.quant_wanx_hip import QuantWanModelHip
     from wan.utils.fm_solvers import FlowMatchScheduler
 
     cfg = WAN_CONFIGS[args.model]
+    # N GPUs = cfg-parallel degree (cond / uncond pass on different GPUs) x Ulysses degree (token sequence sharded)
+    plan = ParallelPlan(world, rank, *ParallelPlan.choose(world, cfg["num_heads"], not args.no_cfg_parallel))
     shape = latent_shape(SIZE_CONFIGS[args.size], args.frames)
-    seq_len = seq_len_for(shape)
+    seq_len = seq_len_for(shape, sp_size=plan.sp_degree)
     torch.backends.cuda.matmul.allow_tf32 = False
 
     fp = synth_model(args.model, dev, seed=0)
-    model = QuantWanModelHip(fp, n_bits=8, sym=False, keep_fp_blocks=not args.no_quality)
+    model = QuantWanModelHip(fp, n_bits=8, sym=False, keep_fp_blocks=(world == 1 and not args.no_quality))
 
     g = torch.Generator(device=dev).manual_seed(42)
     latent0 = torch.randn(shape, generator=g, device=dev)
@@ -158,8 +162,12 @@ def main():
 
     def step(latent, i):
         t = sched.timesteps[i:i + 1]
-        cond = model([latent], t, [ctx_c], seq_len)[0]
-        uncond = model([latent], t, [ctx_u], seq_len)[0]
+        if plan.cfg_degree == 2:  # my half of the GPUs runs ONE of the two passes; a 2 MB all-gather joins them
+            mine = model([latent], t, [ctx_c if plan.cfg_index == 0 else ctx_u], seq_len, plan.sp)[0]
+            cond, uncond = plan.gather_cfg(mine)
+        else:
+            cond = model([latent], t, [ctx_c], seq_len, plan.sp)[0]
+            uncond = model([latent], t, [ctx_u], seq_len, plan.sp)[0]
         noise = uncond + args.guide * (cond - uncond)
         return sched.step(noise, latent)
 
@@ -192,7 +200,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
         "config": {"workload": f"Wan2.1-{args.model} DiT, W8A8 all block linears (W asym per-channel static, A sym per-token dynamic), "
                                f"{args.size}x{args.frames}f, latent {list(shape)}, L={seq_len}, cond+uncond+CFG+scheduler per step",
-                   "attention": "bf16", "parallelism": f"sp{world}"},
+                   "attention": "bf16", "parallelism": plan.describe()},
     }
     if gs:
         ach = gs["ops"] / gs["seconds"]
@@ -200,14 +208,14 @@ def main():
                            "peak": INT8_MFMA_PEAK / 1e12, "unit": "TOP/s", "frac": ach / INT8_MFMA_PEAK, "traffic": None,
                            "launches": gs["launches"], "avg_launch_us": gs["seconds"] / gs["launches"] * 1e6,
                            "gemm_share_of_step": gs["seconds"] / dt}
-    if rank == 0 and not args.no_quality:
+    if rank == 0 and world == 1 and not args.no_quality:
         # deviation of the quantized DiT output from the FP (bf16-autocast) output of the same synthetic model
         t = sched.timesteps[0:1]
         with torch.no_grad():
-            yq = model([latent0], t, [ctx_c], seq_len)[0]
+            yq = model([latent0], t, [ctx_c], seq_len_for(shape))[0]
             model.fp.blocks = model.fp_blocks
             with torch.autocast("cuda", dtype=torch.bfloat16):
-                yf = model.fp([latent0], t, [ctx_c], seq_len)[0]
+                yf = model.fp([latent0], t, [ctx_c], seq_len_for(shape))[0]
         mse = (yq - yf).pow(2).mean().item()
         rng = (yf.max() - yf.min()).item()
         out["quality"] = {"tensor": "DiT output latent (noise_pred)", "rel_l2_vs_fp": ((yq - yf).norm() / yf.norm()).item(),

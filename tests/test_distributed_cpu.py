@@ -1,0 +1,131 @@
+"""The N>1 path on CPU: world_size 2 and 4 under gloo.  Covers the Ulysses all-to-all layout (forward o inverse
+= identity; sequence order == rank order), Ulysses attention == full attention, the row sharding / all-gather,
+and the cfg x sp process-group plan.  The layout code is the same code the GPU path runs over RCCL."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "wan2.1-quantization_amd")
+
+
+def _init(rank, world, port):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _ulysses_worker(rank, world, port, q):
+    try:
+        _init(rank, world, port)
+        from oracle import wan_ref as wr
+        from wan.distributed.parallel import ParallelPlan, SeqParallel
+
+        sp = SeqParallel(None)
+        assert sp.size == world and sp.rank == rank
+        H, d, L = 4, 8, 10 * world
+        g = torch.Generator().manual_seed(0)
+        full = [torch.randn(L, H * d, generator=g) for _ in range(3)]
+        lp = L // world
+        loc = [sp.shard_rows(t).contiguous() for t in full]
+        # identity: gather_heads(scatter_heads(x)) == x, sync and async forms
+        s = sp.scatter_heads(loc[0])
+        assert s.shape == (L, H * d // world)
+        # rank r holds head group r of ALL tokens, in sequence order
+        assert torch.equal(s, full[0].view(L, world, -1)[:, rank])
+        assert torch.equal(sp.gather_heads(s), loc[0])
+        assert torch.equal(sp.gather_heads(sp.scatter_heads(loc[1], async_op=True).wait(), async_op=True).wait(), loc[1])
+        # Ulysses attention == full attention (key padding masked by k_len)
+        k_len = L - 3
+        qs, ks, vs = (sp.scatter_heads(t) for t in loc)
+        hp = H // world
+        o = wr.attention(qs.view(L, hp, d), ks.view(L, hp, d), vs.view(L, hp, d), k_len).reshape(L, hp * d)
+        o_loc = sp.gather_heads(o)
+        ref = wr.attention(full[0].view(L, H, d), full[1].view(L, H, d), full[2].view(L, H, d), k_len).reshape(L, H * d)
+        torch.testing.assert_close(o_loc, ref[rank * lp:(rank + 1) * lp], rtol=1e-5, atol=1e-6)
+        # final all-gather restores the sequence
+        assert torch.equal(sp.all_gather_rows(loc[2]), full[2])
+        assert sp.padded_len(L + 1) == L + world
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def _plan_worker(rank, world, port, q):
+    try:
+        _init(rank, world, port)
+        from wan.distributed.parallel import ParallelPlan
+
+        cfg, sp = ParallelPlan.choose(world, num_heads=12)
+        assert (cfg, sp) == ((2, world // 2) if world % 2 == 0 else (1, world))
+        plan = ParallelPlan(world, rank, cfg, sp)
+        assert plan.sp.size == sp and plan.cfg_index == rank // sp and plan.sp_index == rank % sp
+        mine = torch.full((2, 3), float(plan.cfg_index * 10 + plan.sp_index))
+        cond, uncond = plan.gather_cfg(mine)
+        assert torch.all(cond == plan.sp_index) and torch.all(uncond == 10 + plan.sp_index)
+        if sp > 1:  # the Ulysses group only spans ranks of the same cfg index
+            x = torch.full((2 * sp, 4 * sp), float(rank))
+            s = plan.sp.scatter_heads(x)
+            expect = torch.cat([torch.full((2 * sp, 4), float(plan.cfg_index * sp + r)) for r in range(sp)])
+            assert torch.equal(s, expect)
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def _run(worker, world, port):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_ulysses_layout_and_attention_world2():
+    _run(_ulysses_worker, 2, 29611)
+
+
+def test_ulysses_layout_and_attention_world4():
+    _run(_ulysses_worker, 4, 29612)
+
+
+def test_cfg_x_sp_plan_world2():
+    _run(_plan_worker, 2, 29613)
+
+
+def test_cfg_x_sp_plan_world4():
+    _run(_plan_worker, 4, 29614)
+
+
+def test_plan_choice_rules():
+    from wan.distributed.parallel import ParallelPlan
+
+    assert ParallelPlan.choose(1, 12) == (1, 1)
+    assert ParallelPlan.choose(2, 12) == (2, 1)
+    assert ParallelPlan.choose(4, 12) == (2, 2)
+    assert ParallelPlan.choose(8, 12) == (2, 4)        # 12 heads: pure Ulysses-8 is impossible
+    assert ParallelPlan.choose(8, 40, cfg_parallel=False) == (1, 8)  # 14B, the reference's ulysses_size=8
+    assert ParallelPlan.choose(8, 40) == (2, 4)
+    with pytest.raises(ValueError):
+        ParallelPlan.choose(8, 12, cfg_parallel=False)

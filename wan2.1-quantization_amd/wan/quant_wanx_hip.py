@@ -123,9 +123,11 @@ class WanAttentionBlockWithHipKernel(nn.Module):
         q = fused.quant_sum(x, qs[1], qs[0])
         return q, qs[0], qs[1]
 
-    def forward(self, x, e0, rope, seq_len, ctx_q):
-        """x: fp32 [L, C] residual stream, updated IN PLACE.  e0: fp32 [1, 6, C].  rope: fp32 [pos, d/2, 2].
-        seq_len: number of real (unpadded) tokens.  ctx_q: (int8 [Lc, C], scale [Lc], sum [Lc]) text context."""
+    def forward(self, x, e0, rope, seq_len, ctx_q, sp=None):
+        """x: fp32 [L, C] residual stream (this rank's token shard under sequence parallelism), updated IN PLACE.
+        e0: fp32 [1, 6, C].  rope: fp32 [pos, d/2, 2] for the local tokens.  seq_len: number of real (unpadded)
+        tokens of the WHOLE sequence.  ctx_q: (int8 [Lc, C], scale [Lc], sum [Lc]) text context.
+        sp: wan.distributed.SeqParallel or None."""
         H, d, dt = self.num_heads, self.head_dim, self.act_dtype
         e = self.modulation + e0  # [1, 6, C] fp32
         sa, ca = self.self_attn, self.cross_attn
@@ -133,11 +135,21 @@ class WanAttentionBlockWithHipKernel(nn.Module):
         # ---- self attention: LN*(1+e1)+e0 -> int8 -> q,k,v GEMMs -> RMSNorm+RoPE -> attention -> int8 -> o GEMM (+gate, +res)
         hq, hs, hsum = self._ln_quant(x, None, e[:, 0], e[:, 1])
         q = sa.q(hq, hs, hsum, dt)
-        k = sa.k(hq, hs, hsum, dt)
-        v = sa.v(hq, hs, hsum, dt)
         ops.rmsnorm_rope_(q, sa.norm_q_weight, rope, d, eps=self.eps)
-        ops.rmsnorm_rope_(k, sa.norm_k_weight, rope, d, eps=self.eps)
-        o = ops.attention(q, k, v, H, seq_len)
+        if sp is None or sp.size == 1:
+            k = sa.k(hq, hs, hsum, dt)
+            ops.rmsnorm_rope_(k, sa.norm_k_weight, rope, d, eps=self.eps)
+            v = sa.v(hq, hs, hsum, dt)
+            o = ops.attention(q, k, v, H, seq_len)
+        else:  # Ulysses: the q / k all-to-alls fly under the k / v GEMMs
+            wq = sp.scatter_heads(q, async_op=True)
+            k = sa.k(hq, hs, hsum, dt)
+            ops.rmsnorm_rope_(k, sa.norm_k_weight, rope, d, eps=self.eps)
+            wk = sp.scatter_heads(k, async_op=True)
+            v = sa.v(hq, hs, hsum, dt)
+            wv = sp.scatter_heads(v, async_op=True)
+            o = ops.attention(wq.wait(), wk.wait(), wv.wait(), H // sp.size, seq_len)
+            o = sp.gather_heads(o)
         oq, os_, osum = self._quant(o)
         sa.o(oq, os_, osum, torch.float32, gate=e[0, 2].contiguous(), residual=x, out=x)
 
@@ -185,14 +197,25 @@ class QuantWanModelHip(nn.Module):
         return self._rope_cache[grid]
 
     @torch.no_grad()
-    def forward(self, x, t, context, seq_len):
+    def forward(self, x, t, context, seq_len, sp=None):
+        """WanModel.forward signature for ONE sample; with `sp` (SeqParallel) the token sequence is sharded
+        over the group as usp_dit_forward does (xdit_context_parallel.py:131-142): seq_len must be a multiple
+        of sp.size (WanT2V.generate pads it so, text2video.py:170-172)."""
         assert len(x) == 1, "kernel-mode forward takes one sample (cond and uncond are separate passes)"
         with torch.autocast("cuda", enabled=False):
             h, e, e0, ctx, seq_lens, grids = self.fp.embed(x, t, context, seq_len)
-            h = h[0].float().contiguous()  # [L, C] fp32 residual stream
+            h = h[0].float()  # [seq_len, C] fp32 residual stream
             rope = self._rope(grids[0], h.device)
+            if sp is not None and sp.size > 1:
+                assert seq_len % sp.size == 0
+                lp = seq_len // sp.size
+                h = sp.shard_rows(h)
+                rope = rope[sp.rank * lp:(sp.rank + 1) * lp]  # may be shorter than lp on the last rank: pads stay unrotated
+            h = h.contiguous()
             cq = WanAttentionBlockWithHipKernel._quant(ctx[0].float().contiguous())
             for blk in self.blocks:
-                blk(h, e0.float(), rope, seq_lens[0], cq)
+                blk(h, e0.float(), rope, seq_lens[0], cq, sp)
             out = self.fp.head(h.unsqueeze(0), e)
+            if sp is not None and sp.size > 1:
+                out = sp.all_gather_rows(out[0]).unsqueeze(0)
             return [u.float() for u in self.fp.unpatchify(out, grids)]
