@@ -110,7 +110,8 @@ int wanq_row_minmax(const void* w, int w_dtype, float* row_min, float* row_max, 
                     int64_t rows, int cols, void* stream);
 
 /* Static per-output-channel weight quantisation with given params (fp32 [rows]):
- *   q = clamp(rne(w/delta) - zp, qmin, qmax)  -> int8 codes, and/or fake-quant (q+zp)*delta -> fp32.
+ *   q = clamp(rne(w/delta) - zp, qmin, qmax)  -> fake-quant (q+zp)*delta -> fp32, and/or int8 codes (q saturated to
+ *   [-128,127] on top of [qmin,qmax]: the reference's own clamp is looser than the bit-width).
  *   (base_quantizer.py:56-68; export: wan/quant_wanx_cuda.py:39-53).  q8 / deq may be NULL. */
 int wanq_weight_quant(const void* w, int w_dtype, const float* delta, const float* zp, int qmin, int qmax,
                       int8_t* q8, float* deq, int64_t rows, int cols, void* stream);
@@ -136,6 +137,26 @@ int wanq_rmsnorm_rope(const void* x, int x_dtype, const float* weight, const flo
 int wanq_attention_fwd(const void* q, const void* k, const void* v, void* o, int dtype, int64_t Lq,
                        int64_t Lk, int heads, int head_dim, int64_t q_stride, int64_t k_stride,
                        int64_t v_stride, int64_t o_stride, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ViDiT activation transform fused with the per-token quantiser:
+ *   y = hadU(x * premul),   hadU = (H_K (x) H_128) / sqrt(cols)   (natural-order Walsh-Hadamard on each
+ *   128-wide block, then the +-1 matrix hadk[K,K] across blocks)
+ * premul fp32[cols] = channel_mask * rotation_signs (either may be all ones), or NULL; had_k = 0 disables the
+ * rotation, otherwise cols must equal had_k * 128 (1536 -> 12, 5120 -> 40, 2^p -> 2^p/128 with a Sylvester hadk).
+ * Equals `x*channel_mask -> (x.double() @ rotation_matrix)` of ViDiTQuantizedLinear.forward
+ * (ViDiT-Q/quant_utils/qdiff/viditq/viditq_quant_layer.py:62-63) because row i of the random Hadamard
+ * matrix is sign_i * hadU(e_i) (quarot_utils.py:186-192); evaluated in fp32 with O(n log n + nK) adds instead
+ * of a dense fp64 GEMM.  Outputs: fp (out_fp) and/or int8 codes + scale (+sum), as wanq_quant_rows. */
+int wanq_rotate_quant_rows(const void* x, int x_dtype, const float* premul, const float* hadk, int had_k,
+                           void* out_fp, int out_dtype, int8_t* q, void* scale, void* sum, int vec_dtype,
+                           int64_t rows, int cols, int act, void* stream);
+
+/* LayerNorm -> modulate (as wanq_layernorm_rows) -> ViDiT transform -> int8 quantise, one kernel. */
+int wanq_layernorm_rotate_quant_rows(const void* x, int x_dtype, const void* gamma, const void* mshift,
+                                     const void* mscale, int mod_dtype, int64_t mod_stride, int64_t rows_per_batch,
+                                     float eps, const float* premul, const float* hadk, int had_k, int8_t* q,
+                                     void* scale, void* sum, int vec_dtype, int64_t rows, int cols, void* stream);
 
 #ifdef __cplusplus
 }

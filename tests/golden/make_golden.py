@@ -229,6 +229,34 @@ def gen_a5_a4():
          w_delta=vl.w_quantizer.delta.reshape(-1), w_zp=vl.w_quantizer.zero_point.reshape(-1), y=y)
 
 
+def gen_a4_1536():
+    """ViDiT layer at the real Wan hidden size (in=1536 = 12 x 128), small out/tokens to keep the fixture small."""
+    g = torch.Generator().manual_seed(1536)
+    n, out = 1536, 24
+    lin = torch.nn.Linear(n, out)
+    lin.weight.data = torch.randn(out, n, generator=g) * 0.05
+    lin.weight.data[:, 11] *= 5.0
+    lin.bias.data = torch.randn(out, generator=g) * 0.1
+    cfg = OmegaConf.create({"weight": {"n_bits": 8, "sym": False}, "act": {"n_bits": 8, "sym": True},
+                            "viditq": {"alpha": 0.5665, "layer_name_regex": ""}})
+    vl = ViDiTQuantizedLinear(n, out, True, "cpu", cfg, lin)
+    vl.a_quantizer.module_name = "golden"
+    act_mask = outlier_acts(g, 32, n).abs().max(dim=0)[0]
+    act_mask = torch.where(act_mask < 1e-3, torch.tensor(1e-3), act_mask)
+    vl.get_channel_mask(act_mask)
+    s = (torch.randint(0, 2, (n,), generator=g) * 2 - 1).to(torch.float64)
+    vl.rotation_matrix = hadamard_from_signs(s)
+    vl.update_quantized_weight_rotated_and_scaled()
+    x = outlier_acts(g, 9, n).reshape(1, 9, n)
+    # the transformed activation and its integer codes, as forward computes them (viditq_quant_layer.py:62-68)
+    xt = torch.matmul((x * vl.channel_mask.reshape(1, 1, n)).double(), vl.rotation_matrix).to(torch.float32).reshape(9, n)
+    q = vl.a_quantizer.quantize(xt.clone())
+    y = vl(x)
+    save("a4_viditq_1536", x=x, w=lin.weight.data, b=lin.bias.data, act_mask=act_mask, signs=s, channel_mask=vl.channel_mask,
+         w_final=vl.weight.data, w_delta=vl.w_quantizer.delta.reshape(-1), w_zp=vl.w_quantizer.zero_point.reshape(-1),
+         x_rot=xt, x_q=q.to(torch.int32), x_delta=vl.a_quantizer.delta.reshape(-1), y=y)
+
+
 # ----------------------------------------------------------------------------- A8
 def gen_a8():
     g = torch.Generator().manual_seed(5)
@@ -295,5 +323,6 @@ if __name__ == "__main__":
     gen_a1()
     gen_a3()
     gen_a5_a4()
+    gen_a4_1536()
     gen_a8()
     gen_kbench()

@@ -1,0 +1,195 @@
+"""GPU parity of the qdiff drop-in modules (real int8 compute) against golden vectors produced by the
+reference's own fake-quant modules, and of the fused ViDiT transform kernel against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import qdiff_ref as qr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+torch.set_grad_enabled(False)
+
+
+def t(a, dtype=None):
+    x = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return x.to(dtype) if dtype is not None else x
+
+
+def cfg(**extra):
+    from qdiff import config as qcfg
+
+    return qcfg.create(dict({"weight": {"n_bits": 8, "sym": False}, "act": {"n_bits": 8, "sym": True}}, **extra))
+
+
+@pytest.mark.parametrize("n", [1536, 5120])
+def test_rotation_kernel_vs_reference_hadamard_products(golden, n):
+    """out_fp of wanq_rotate_quant_rows == hadU(x) of the reference (golden a5), fp32 vs fp64: 1e-5."""
+    import viditq_extension.fused as fused
+    from qdiff.quarot import quarot_utils as qu
+
+    g = golden(f"a5_hadamard_{n}")
+    x = t(g["x"], torch.float32)
+    rot = qu.kernel_rotation_params(n, DEV)
+    out = torch.empty_like(x)
+    fused.rotate_quant(x, None, rot, None, None, out_fp=out, quantize=False)
+    np.testing.assert_allclose(out.cpu().numpy(), g["hadU_x"], rtol=0, atol=2e-5)
+    # with a sign pre-multiplier it is x @ R
+    s = t(g["signs"], torch.float32)
+    fused.rotate_quant(x, s, rot, None, None, out_fp=out, quantize=False)
+    ref = qr.matmul_hadU(g["x"] * g["signs"])
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("n,rows", [(1536, 131), (5120, 37), (4096, 16), (128, 9)])
+def test_rotate_quant_codes_vs_oracle(n, rows):
+    import viditq_extension.fused as fused
+    from qdiff.quarot import quarot_utils as qu
+
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(rows, n, generator=g) * torch.exp(torch.randn(n, generator=g))
+    pm = (torch.rand(n, generator=g) + 0.5) * (torch.randint(0, 2, (n,), generator=g) * 2 - 1)
+    ref = qr.matmul_hadU((x.double() * pm.double()).numpy()).astype(np.float32)
+    oq, oscale = qr.dynamic_quantize_sym(ref)
+    scale = torch.zeros(rows, device=DEV)
+    ssum = torch.zeros(rows, device=DEV)
+    q = fused.rotate_quant(x.to(DEV), pm.to(DEV), qu.kernel_rotation_params(n, DEV), ssum, scale)
+    np.testing.assert_allclose(scale.cpu().numpy(), oscale, rtol=2e-6)
+    d = np.abs(q.cpu().numpy().astype(np.int32) - oq)
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3  # fp32 transform vs fp64: codes move only at .5 boundaries
+    np.testing.assert_allclose(ssum.cpu().numpy(), q.cpu().numpy().astype(np.int64).sum(1) * scale.cpu().numpy().astype(np.float64), rtol=1e-6, atol=1e-6)
+
+
+def test_layernorm_rotate_quant_vs_oracle():
+    import viditq_extension.fused as fused
+    from oracle import kernel_ref as kr
+    from qdiff.quarot import quarot_utils as qu
+
+    n, rows = 1536, 70
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(rows, n, generator=g) * 2 + 0.1
+    sh, sc = torch.randn(1, n, generator=g) * 0.2, torch.randn(1, n, generator=g) * 0.2
+    pm = (torch.rand(n, generator=g) + 0.5) * (torch.randint(0, 2, (n,), generator=g) * 2 - 1)
+    h = kr.layernorm_t2i(x.numpy(), None, sh.numpy(), sc.numpy(), 1e-6, rows)
+    ref = qr.matmul_hadU(h * pm.double().numpy()).astype(np.float32)
+    oq, oscale = qr.dynamic_quantize_sym(ref)
+    q = torch.empty(rows, n, dtype=torch.int8, device=DEV)
+    scale, ssum = torch.zeros(rows, device=DEV), torch.zeros(rows, device=DEV)
+    fused.layernorm_rotate_quant(q, x.to(DEV), None, sh.to(DEV), sc.to(DEV), pm.to(DEV), qu.kernel_rotation_params(n, DEV), ssum, scale, 1e-6)
+    np.testing.assert_allclose(scale.cpu().numpy(), oscale, rtol=1e-5)
+    d = np.abs(q.cpu().numpy().astype(np.int32) - oq)
+    assert d.max() <= 1 and (d != 0).mean() < 3e-3
+
+
+def test_quantized_linear_vs_reference_golden(golden):
+    """qdiff.QuantizedLinear (int8 GEMM inside) == the reference's QuantizedLinear.forward output (golden a3)."""
+    from qdiff.base.quant_layer import QuantizedLinear
+
+    g = golden("a3_qlinear")
+    lin = torch.nn.Linear(64, 48).to(DEV)
+    lin.weight.data, lin.bias.data = t(g["w"]), t(g["b"])
+    ql = QuantizedLinear(64, 48, True, DEV, cfg(), lin)
+    assert np.array_equal(ql.weight.data.cpu().numpy(), g["w_dequant"])  # the fake-quantised weight, bit for bit
+    assert np.array_equal(ql.w_quantizer.delta.reshape(-1).cpu().numpy(), g["w_delta"])
+    assert np.array_equal(ql.w_quantizer.zero_point.reshape(-1).cpu().numpy(), g["w_zp"])
+    y = ql(t(g["x"]))
+    assert y.shape == g["y"].shape
+    np.testing.assert_allclose(y.cpu().numpy(), g["y"], rtol=2e-5, atol=2e-5)
+    # quantizers on their own follow the reference API
+    x2 = t(g["x"]).reshape(-1, 64)
+    deq = ql.a_quantizer(x2)
+    np.testing.assert_array_equal(deq.cpu().numpy(), qr.dynamic_fake_quant_sym(g["x"].reshape(-1, 64)))
+    assert ql.a_quantizer.delta.shape == (33, 1)
+    ql.quant_mode = False
+    np.testing.assert_allclose(ql(t(g["x"])).cpu().numpy(), (g["x"] @ g["w"].T + g["b"]), rtol=1e-4, atol=1e-4)
+
+
+def test_viditq_linear_vs_reference_golden(golden):
+    """ViDiTQuantizedLinear at in_features 1536: channel mask, double-quantised rotated weight and forward output
+    against what the reference's own module produced (golden a4_viditq_1536)."""
+    from qdiff.viditq.viditq_quant_layer import ViDiTQuantizedLinear
+
+    g = golden("a4_viditq_1536")
+    n, out = 1536, 24
+    lin = torch.nn.Linear(n, out).to(DEV)
+    lin.weight.data, lin.bias.data = t(g["w"]), t(g["b"])
+    vl = ViDiTQuantizedLinear(n, out, True, DEV, cfg(viditq={"alpha": 0.5665, "layer_name_regex": ""}), lin)
+    vl.get_channel_mask(t(g["act_mask"]))
+    np.testing.assert_allclose(vl.channel_mask.cpu().numpy(), g["channel_mask"], rtol=3e-7)  # powf ulp
+    vl.channel_mask = t(g["channel_mask"])
+    vl.rotation_signs = torch.from_numpy(g["signs"])
+    vl.update_quantized_weight_rotated_and_scaled()
+    assert np.array_equal(vl.w_quantizer.delta.reshape(-1).cpu().numpy(), g["w_delta"])
+    assert np.array_equal(vl.w_quantizer.zero_point.reshape(-1).cpu().numpy(), g["w_zp"])
+    assert np.array_equal(vl.weight.data.cpu().numpy(), g["w_final"])
+    # activation codes: fp32 fast transform vs the reference's fp64 dense product
+    q, scale, _ = vl.a_quantizer.quantize_int8(t(g["x"]).reshape(-1, n), *vl._act_transform())
+    np.testing.assert_allclose(scale.cpu().numpy(), g["x_delta"], rtol=2e-6)
+    d = np.abs(q.cpu().numpy().astype(np.int32) - g["x_q"].astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3
+    y = vl(t(g["x"]))
+    # one flipped code changes y by <= delta_x * |w|: compare at the level of the quantisation step
+    assert np.abs(y.cpu().numpy() - g["y"]).max() < 5e-3 * np.abs(g["y"]).max() + 1e-3
+    # rotation_matrix property materialises the reference's matrix
+    R = vl.rotation_matrix
+    np.testing.assert_allclose(R.cpu().numpy()[[0, 1, 777, n - 1]], qr.hadamard_from_signs(g["signs"])[[0, 1, 777, n - 1]], atol=1e-15)
+
+
+def test_surgery_save_load_roundtrip_and_mixed_precision():
+    """quant_layer_refactor_ / save / load / bitwidth_refactor_ on a toy module tree."""
+    import torch.nn as nn
+
+    from qdiff import config as qcfg
+    from qdiff.base.quant_layer import QuantizedLinear
+    from qdiff.base.quant_model import QuantModel
+    from qdiff.viditq.viditq_quant_layer import ViDiTQuantizedLinear
+
+    class Toy(QuantModel):
+        def __init__(self, q_cfg):
+            nn.Module.__init__(self)
+            self.q_cfg = q_cfg
+            self.blocks = nn.ModuleList([nn.ModuleDict({"q": nn.Linear(1536, 64), "ffn": nn.Linear(64, 64)}) for _ in range(2)])
+            self.head = nn.Linear(64, 8)
+
+        def forward(self, x):
+            return self.head(sum(b["ffn"](b["q"](x)) for b in self.blocks))
+
+    torch.manual_seed(0)
+    c = cfg(viditq={"alpha": 0.5665, "layer_name_regex": r"\.q$"}, remain_fp_regex="head")
+    m = Toy(c).to(DEV)
+    fp_state = {k: v.clone() for k, v in m.state_dict().items()}
+    m.quant_layer_refactor()
+    assert isinstance(m.blocks[0]["q"], ViDiTQuantizedLinear) and type(m.blocks[1]["ffn"]) is QuantizedLinear
+    assert type(m.head) is nn.Linear and m.blocks[0]["q"].module_name == "blocks.0.q"
+    for b in m.blocks:
+        b["q"].get_channel_mask(torch.rand(1536, device=DEV) + 0.5)
+        b["q"].get_rotation_matrix()
+        b["q"].update_quantized_weight_rotated_and_scaled()
+    m.set_init_done()
+    x = torch.randn(1, 50, 1536, device=DEV)
+    y0 = m(x)
+    d = m.save_quant_param_dict()
+    assert set(d) == {f"blocks.{i}.{l}.{q}" for i in range(2) for l in ("q", "ffn") for q in ("w_quantizer", "a_quantizer")}
+    assert d["blocks.0.q.w_quantizer"]["rotation_matrix"] is None and d["blocks.0.q.w_quantizer"]["channel_mask"].shape == (1536,)
+    # a fresh model with the same FP weights + the saved dict reproduces the outputs exactly
+    m2 = Toy(c).to(DEV)
+    m2.load_state_dict(fp_state)
+    m2.quant_layer_refactor()
+    m2.load_quant_param_dict({k: {kk: (vv.cpu() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in d.items()})
+    m2.set_init_done()
+    assert torch.equal(m2(x), y0)
+
+    # mixed precision: ffn weights to 4 bit
+    cm = qcfg.create({"weight": {"n_bits": [4, 8], "i_bitwidth": 1, "sym": False}, "act": {"n_bits": 8, "sym": True},
+                      "remain_fp_regex": "head",
+                      "mixed_precision": {"weight": {"layer_name_regex": ["", "ffn", ""]}, "act": {"layer_name_regex": ["", ""]}}})
+    m3 = Toy(cm).to(DEV)
+    m3.quant_layer_refactor()
+    w8 = m3.blocks[0]["ffn"].int_weight.clone()
+    m3.bitwidth_refactor()
+    f = m3.blocks[0]["ffn"]
+    assert f.w_quantizer.n_bits == 4 and f.int_weight.min() >= -8 and f.int_weight.max() <= 7 and not torch.equal(w8, f.int_weight)
+    assert m3.blocks[0]["q"].w_quantizer.n_bits == 8
+    deq = qr.static_fake_quant(f.fp_module.weight.data.cpu().numpy(), 4, False)[0]
+    assert np.array_equal(f.weight.data.cpu().numpy(), deq)
+    assert torch.isfinite(m3(x)).all()

@@ -188,3 +188,17 @@ def test_torch_quantizers_match_numpy(golden):
     assert np.array_equal(fl.weight.numpy(), g["w_final"])
     y = fl(torch.from_numpy(g["x"]).reshape(-1, g["x"].shape[-1])).numpy()
     np.testing.assert_allclose(y, g["y"].reshape(y.shape), rtol=2e-5, atol=2e-5)
+
+
+def test_a4_viditq_layer_1536(golden):
+    g = golden("a4_viditq_1536")
+    R = qr.hadamard_from_signs(g["signs"])
+    xr = qr.vidit_act_transform(g["x"].reshape(-1, 1536), g["channel_mask"], R)
+    assert np.array_equal(xr, g["x_rot"])
+    q, d = qr.dynamic_quantize_sym(xr)
+    assert np.array_equal(q, g["x_q"].astype(np.int32)) and np.array_equal(d, g["x_delta"])
+    w_final, delta, zp = qr.vidit_weight(g["w"], g["channel_mask"], R, 8, False)
+    assert np.array_equal(delta, g["w_delta"]) and np.array_equal(zp, g["w_zp"]) and np.array_equal(w_final, g["w_final"])
+    # the fast transform used by the product equals the dense product with R
+    np.testing.assert_allclose(qr.matmul_hadU((g["x"].reshape(-1, 1536) * g["channel_mask"]).astype(np.float64) * g["signs"]),
+                               g["x_rot"], rtol=0, atol=2e-6)

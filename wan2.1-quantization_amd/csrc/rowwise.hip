@@ -34,6 +34,11 @@ struct RowParams {
   int cols;
   int act;
   int static_amax;
+  // ViDiT transform before quantisation (Q/viditq/viditq_quant_layer.py:62-63): y = hadU(x * premul)
+  const float* premul;  // [cols] channel_mask * rotation signs, or NULL
+  const float* hadk;    // [K, K] +-1 matrix (row-major) or NULL when K == 1
+  int had_k;            // 0 = no rotation; else cols == had_k * 128
+  float had_div;        // fp32 sqrt(cols): the reference divides by torch.tensor(n).sqrt()
 };
 
 __device__ __forceinline__ void load8_rt(const void* base, int dt, int64_t elem, float (&v)[8]) {
@@ -85,13 +90,78 @@ struct RowReduce {
   }
 };
 
+// Hadamard rotation (H_K (x) H_128) / sqrt(n) of a row held in registers.  With 8-element chunks, element e =
+// 8*chunk + j has block index k = chunk >> 4 and in-block index r = 8*(chunk & 15) + j, and chunk & 15 == lane & 15:
+// the 128-point Walsh-Hadamard transform is 3 in-register stages (bits of j) + 4 cross-lane stages (lane bits
+// 0..3, inside a DPP row); the K x K mixing goes through LDS ([k][128] fp32, conflict-free b128 reads).
+template <int WPR, int NCH>
+__device__ __forceinline__ void hadamard_rows(float (&v)[NCH][8], const bool (&ok)[NCH], float* rowbuf, const float* hk_lds,
+                                              int K, float inv_div, int lane, int sub) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+#pragma unroll
+    for (int h = 1; h < 8; h <<= 1)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (!(j & h)) {
+          const float a = v[i][j], b = v[i][j | h];
+          v[i][j] = a + b;
+          v[i][j | h] = a - b;
+        }
+#pragma unroll
+    for (int bit = 1; bit < 16; bit <<= 1) {
+      const bool up = (lane & bit) != 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float o = __shfl_xor(v[i][j], bit, 64);
+        v[i][j] = up ? o - v[i][j] : v[i][j] + o;
+      }
+    }
+  }
+  if (K == 1) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] *= inv_div;
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+    if (ok[i]) {
+      const int chunk = sub * 64 + lane + i * 64 * WPR;
+      float* dst = rowbuf + (chunk >> 4) * 128 + (chunk & 15) * 8;
+      *reinterpret_cast<float4*>(dst) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+      *reinterpret_cast<float4*>(dst + 4) = make_float4(v[i][4], v[i][5], v[i][6], v[i][7]);
+    }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+    if (ok[i]) {
+      const int chunk = sub * 64 + lane + i * 64 * WPR;
+      const float* hrow = hk_lds + (chunk >> 4) * K;
+      const float* src = rowbuf + (chunk & 15) * 8;
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int k2 = 0; k2 < K; ++k2) {
+        const float sgn = hrow[k2];
+        const float4 a = *reinterpret_cast<const float4*>(src + k2 * 128);
+        const float4 b = *reinterpret_cast<const float4*>(src + k2 * 128 + 4);
+        acc[0] += sgn * a.x; acc[1] += sgn * a.y; acc[2] += sgn * a.z; acc[3] += sgn * a.w;
+        acc[4] += sgn * b.x; acc[5] += sgn * b.y; acc[6] += sgn * b.z; acc[7] += sgn * b.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = acc[j] * inv_div;
+    }
+}
+
 template <int WPR, int NCH, bool LN>
 __global__ __launch_bounds__(256) void rowwise_kernel(const RowParams p) {
   __shared__ float red_slots[4 * 4];
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];  // rotation only: hadK [K*K] then row buffers
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int64_t row = (WPR == 1) ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
-  if (WPR == 1 && row >= p.rows) return;  // whole wave leaves; no barriers on this path
+  const bool dead = (WPR == 1 && row >= p.rows);  // surplus wave of the last workgroup
+  if (dead && !p.had_k) return;                   // (the rotation path has workgroup barriers: stay, but touch nothing)
   RowReduce<WPR> red{red_slots, wave};
   const int sub = (WPR == 1) ? 0 : wave;
   const int C = p.cols;
@@ -102,7 +172,7 @@ __global__ __launch_bounds__(256) void rowwise_kernel(const RowParams p) {
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c0 = (sub * 64 + lane + i * 64 * WPR) * 8;
-    ok[i] = c0 < C;
+    ok[i] = c0 < C && !dead;
     if (ok[i]) {
       load8_rt(p.x, p.x_dtype, rbase + c0, v[i]);
     } else {
@@ -155,6 +225,28 @@ __global__ __launch_bounds__(256) void rowwise_kernel(const RowParams p) {
       for (int j = 0; j < 8; ++j) v[i][j] = gelu_tanh_f32(v[i][j]);
   }
 
+  if (p.premul) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (ok[i]) {
+        float pm[8];
+        Io<F32>::load8(p.premul, (sub * 64 + lane + i * 64 * WPR) * 8, pm);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] *= pm[j];
+      }
+  }
+  if (p.had_k) {
+    const int K = p.had_k;
+    const int kk = (K > 1) ? K * K : 0;
+    if (K > 1) {
+      for (int t = threadIdx.x; t < kk; t += 256) dyn_lds[t] = p.hadk[t];
+      __syncthreads();
+    }
+    // one row buffer per wave when a wave owns a row, one per workgroup otherwise
+    float* rowbuf = dyn_lds + ((kk + 3) & ~3) + ((WPR == 1) ? wave * C : 0);
+    hadamard_rows<WPR, NCH>(v, ok, rowbuf, dyn_lds, K, 1.0f / p.had_div, lane, sub);
+  }
+
   if (p.out_fp) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
@@ -164,7 +256,7 @@ __global__ __launch_bounds__(256) void rowwise_kernel(const RowParams p) {
 
   float amax;
   if (p.static_amax) {
-    amax = vec_load(p.scale, p.vec_dtype, row);
+    amax = dead ? 1.f : vec_load(p.scale, p.vec_dtype, row);
   } else {
     float m = 0.f;
 #pragma unroll
@@ -192,18 +284,23 @@ __global__ __launch_bounds__(256) void rowwise_kernel(const RowParams p) {
   }
   if (p.sum) {
     const int tot = red.isum(isum, 3);
-    if (lane == 0 && sub == 0) vec_store(p.sum, p.vec_dtype, row, (float)tot * scale);
+    if (lane == 0 && sub == 0 && !dead) vec_store(p.sum, p.vec_dtype, row, (float)tot * scale);
   }
-  if (!p.static_amax && lane == 0 && sub == 0) vec_store(p.scale, p.vec_dtype, row, scale);
+  if (!p.static_amax && lane == 0 && sub == 0 && !dead) vec_store(p.scale, p.vec_dtype, row, scale);
 }
 
 template <bool LN>
 static int launch_rowwise(const RowParams& p, hipStream_t st, const char* what) {
   const int chunks = p.cols / 8;
   const int64_t rows = p.rows;
+  size_t dyn = 0;
+  if (p.had_k) {
+    const int kk = p.had_k > 1 ? ((p.had_k * p.had_k + 3) & ~3) : 0;
+    dyn = (size_t)(kk + (chunks <= 256 ? 4 : 1) * p.cols) * sizeof(float);
+  }
 #define WANQ_RW(WPR, NCH)                                                                       \
   hipLaunchKernelGGL((rowwise_kernel<WPR, NCH, LN>), dim3((unsigned)((WPR) == 1 ? (rows + 3) / 4 : rows)), \
-                     dim3(256), 0, st, p)
+                     dim3(256), dyn, st, p)
   if (chunks <= 64) WANQ_RW(1, 1);
   else if (chunks <= 128) WANQ_RW(1, 2);
   else if (chunks <= 192) WANQ_RW(1, 3);
@@ -356,8 +453,8 @@ __global__ __launch_bounds__(256) void weight_quant_kernel(const void* w, int dt
     for (int j = 0; j < 8; ++j) {
       // rne(w/delta) - zp, clamp   (base_quantizer.py:64-67); true division: runs once per model
       float t = rintf(v[j] / d) - z;
-      t = fminf(fmaxf(t, (float)qmin), (float)qmax);
-      qi[j] = (int)t;
+      t = fminf(fmaxf(t, (float)qmin), (float)qmax);  // the reference's (loose) clamp for the fake-quant value
+      qi[j] = (int)fminf(fmaxf(t, -128.f), 127.f);     // int8 storage saturates on top of it
       v[j] = (t + z) * d;
     }
     if (q8)
@@ -460,11 +557,60 @@ extern "C" int wanq_weight_quant(const void* w, int w_dtype, const float* delta,
                                  int8_t* q8, float* deq, int64_t rows, int cols, void* stream) {
   WANQ_REQUIRE(w && delta && zp && (q8 || deq), WANQ_E_ARG, "wanq_weight_quant: NULL pointer");
   WANQ_REQUIRE(is_fp(w_dtype), WANQ_E_ARG, "wanq_weight_quant: bad dtype %d", w_dtype);
-  WANQ_REQUIRE(qmin < qmax && (!q8 || (qmin >= -128 && qmax <= 127)), WANQ_E_ARG, "wanq_weight_quant: bad clamp range [%d,%d]", qmin, qmax);
+  WANQ_REQUIRE(qmin < qmax, WANQ_E_ARG, "wanq_weight_quant: bad clamp range [%d,%d]", qmin, qmax);
   if (int e = check_rows_cols("wanq_weight_quant", rows, cols)) return e;
   if (rows == 0) return WANQ_OK;
   const int64_t total = rows * (cols / 8);
   const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(weight_quant_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, w_dtype, delta, zp, qmin, qmax, q8, deq, rows, cols);
   return check_launch("wanq_weight_quant");
+}
+
+// ------------------------------------------------------------------------------ ViDiT scale + rotate + quantise
+static int check_rotation(const char* what, const float* premul, const float* hadk, int had_k, int cols) {
+  WANQ_REQUIRE(had_k >= 0 && had_k <= 128, WANQ_E_SHAPE, "%s: had_k=%d out of range", what, had_k);
+  if (had_k) {
+    WANQ_REQUIRE(cols == had_k * 128, WANQ_E_SHAPE,
+                 "%s: rotation needs cols == had_k * 128 (cols=%d, had_k=%d): the transform is H_K (x) H_128", what, cols, had_k);
+    WANQ_REQUIRE(had_k == 1 || hadk, WANQ_E_ARG, "%s: hadk matrix required for had_k > 1", what);
+  }
+  (void)premul;
+  return WANQ_OK;
+}
+
+extern "C" int wanq_rotate_quant_rows(const void* x, int x_dtype, const float* premul, const float* hadk, int had_k,
+                                      void* out_fp, int out_dtype, int8_t* q, void* scale, void* sum, int vec_dtype,
+                                      int64_t rows, int cols, int act, void* stream) {
+  WANQ_REQUIRE(x && (q || out_fp), WANQ_E_ARG, "wanq_rotate_quant_rows: need x and at least one of out_fp / q");
+  WANQ_REQUIRE(is_fp(x_dtype) && (!out_fp || is_fp(out_dtype)), WANQ_E_ARG, "wanq_rotate_quant_rows: bad dtype code");
+  WANQ_REQUIRE(!q || (scale && is_vec(vec_dtype)), WANQ_E_ARG, "wanq_rotate_quant_rows: q needs scale and a valid vec dtype");
+  WANQ_REQUIRE(act == 0 || act == 1, WANQ_E_ARG, "wanq_rotate_quant_rows: act must be 0 or 1");
+  if (int e = check_rows_cols("wanq_rotate_quant_rows", rows, cols)) return e;
+  if (int e = check_rotation("wanq_rotate_quant_rows", premul, hadk, had_k, cols)) return e;
+  if (rows == 0) return WANQ_OK;
+  RowParams p{};
+  p.x = x; p.x_dtype = x_dtype; p.out_fp = out_fp; p.out_dtype = out_dtype; p.q = q; p.scale = scale; p.sum = sum;
+  p.vec_dtype = vec_dtype; p.rows = rows; p.cols = cols; p.act = act; p.rows_per_batch = 1;
+  p.premul = premul; p.hadk = hadk; p.had_k = had_k; p.had_div = sqrtf((float)cols);
+  return launch_rowwise<false>(p, (hipStream_t)stream, "wanq_rotate_quant_rows");
+}
+
+extern "C" int wanq_layernorm_rotate_quant_rows(const void* x, int x_dtype, const void* gamma, const void* mshift,
+                                                const void* mscale, int mod_dtype, int64_t mod_stride,
+                                                int64_t rows_per_batch, float eps, const float* premul, const float* hadk,
+                                                int had_k, int8_t* q, void* scale, void* sum, int vec_dtype, int64_t rows,
+                                                int cols, void* stream) {
+  WANQ_REQUIRE(x && q && scale, WANQ_E_ARG, "wanq_layernorm_rotate_quant_rows: NULL pointer");
+  WANQ_REQUIRE(is_fp(x_dtype) && is_vec(vec_dtype), WANQ_E_ARG, "wanq_layernorm_rotate_quant_rows: bad dtype code");
+  WANQ_REQUIRE(!(gamma || mshift || mscale) || is_fp(mod_dtype), WANQ_E_ARG, "wanq_layernorm_rotate_quant_rows: bad mod dtype");
+  WANQ_REQUIRE(rows_per_batch >= 1, WANQ_E_ARG, "wanq_layernorm_rotate_quant_rows: rows_per_batch must be >= 1");
+  if (int e = check_rows_cols("wanq_layernorm_rotate_quant_rows", rows, cols)) return e;
+  if (int e = check_rotation("wanq_layernorm_rotate_quant_rows", premul, hadk, had_k, cols)) return e;
+  if (rows == 0) return WANQ_OK;
+  RowParams p{};
+  p.x = x; p.x_dtype = x_dtype; p.gamma = gamma; p.mshift = mshift; p.mscale = mscale; p.mod_dtype = mod_dtype;
+  p.mod_stride = mod_stride; p.rows_per_batch = rows_per_batch; p.eps = eps; p.q = q; p.scale = scale; p.sum = sum;
+  p.vec_dtype = vec_dtype; p.rows = rows; p.cols = cols;
+  p.premul = premul; p.hadk = hadk; p.had_k = had_k; p.had_div = sqrtf((float)cols);
+  return launch_rowwise<true>(p, (hipStream_t)stream, "wanq_layernorm_rotate_quant_rows");
 }

@@ -198,3 +198,72 @@ def weight_quant(w, delta, zero_point, qmin, qmax, want_int8=True, want_dequant=
         _C.call("wanq_weight_quant", _C.ptr(w), _C.dt(w), _C.ptr(delta), _C.ptr(zero_point), int(qmin), int(qmax),
                 _C.ptr(q8), _C.ptr(dq), rows, cols, _C.stream())
     return q8, dq
+
+
+# ---- ViDiT activation transform fused with the quantiser (no counterpart in the reference extension: its kernel mode
+#      skips the transform altogether; simulation mode does x*mask -> x.double() @ R in torch)
+def _rotation_args(premul, rotation, cols, device):
+    had_k, hadk = (0, None) if rotation is None else rotation
+    if premul is not None:
+        _C.check_gpu("premul", premul)
+        _C.check_dtype("premul", premul, torch.float32)
+        _C.check_contig("premul", premul)
+        _C.check_shape("premul", premul, cols)
+    if hadk is not None:
+        _C.check_gpu("hadk", hadk)
+        _C.check_dtype("hadk", hadk, torch.float32)
+        _C.check_contig("hadk", hadk)
+        _C.check_shape("hadk", hadk, had_k, had_k)
+    return int(had_k), hadk
+
+
+def rotate_quant(input, premul, rotation, sum_output, scaling, act=0, out_fp=None, quantize=True):
+    """y = hadU(input * premul) -> int8 codes (+ scale / sum) and / or the fp result in `out_fp`.
+    rotation: None or (had_k, hadk fp32 [had_k, had_k] | None) from qdiff.quarot.quarot_utils.kernel_rotation_params."""
+    rows, cols = _rows_cols("input", input)
+    had_k, hadk = _rotation_args(premul, rotation, cols, input.device)
+    q = None
+    if quantize:
+        _check_vec("scaling", scaling, rows)
+        if sum_output is not None:
+            _check_vec("sum_output", sum_output, rows)
+        q = torch.empty(input.shape, dtype=torch.int8, device=input.device)
+    if out_fp is not None:
+        _rows_cols("out_fp", out_fp)
+    with torch.cuda.device(input.device):
+        _C.call("wanq_rotate_quant_rows", _C.ptr(input), _C.dt(input), _C.ptr(premul), _C.ptr(hadk), had_k,
+                _C.ptr(out_fp), _C.dt(out_fp) if out_fp is not None else _C.F32, _C.ptr(q),
+                _C.ptr(scaling) if quantize else None, _C.ptr(sum_output) if quantize else None,
+                _C.dt(scaling) if quantize else _C.F32, rows, cols, act, _C.stream())
+    return q
+
+
+def layernorm_rotate_quant(output, input, weight, shift_msa, scale_msa, premul, rotation, sum_output, scaling, epsilon):
+    """layernorm_nobias_t2i_quant_sum_fuse with the ViDiT transform between the modulation and the quantiser."""
+    rows, cols = _rows_cols("input", input)
+    had_k, hadk = _rotation_args(premul, rotation, cols, input.device)
+    _C.check_gpu("output", output)
+    _C.check_dtype("output", output, torch.int8)
+    _C.check_contig("output", output)
+    _check_vec("scaling", scaling, rows)
+    if sum_output is not None:
+        _check_vec("sum_output", sum_output, rows)
+    batch, mod_stride = 1, 0
+    mods = [m for m in (weight, shift_msa, scale_msa) if m is not None]
+    for m in mods:
+        _C.check_gpu("weight/shift/scale", m)
+        _C.check_dtype("weight/shift/scale", m, torch.float32)
+    if weight is not None:
+        _C.check_shape("weight", weight, cols)
+        weight = weight.contiguous()
+    ref = shift_msa if shift_msa is not None else scale_msa
+    if ref is not None:
+        batch = ref.shape[0]
+        mod_stride = ref.stride(0)
+        for m in (shift_msa, scale_msa):
+            if m is not None and (m.dim() != 2 or m.shape != ref.shape or m.stride(1) != 1 or m.stride(0) != mod_stride):
+                raise RuntimeError("shift_msa / scale_msa must be [batch, cols] views with equal strides")
+    with torch.cuda.device(input.device):
+        _C.call("wanq_layernorm_rotate_quant_rows", _C.ptr(input), _C.dt(input), _C.ptr(weight), _C.ptr(shift_msa),
+                _C.ptr(scale_msa), _C.F32, mod_stride, rows // batch, float(epsilon), _C.ptr(premul), _C.ptr(hadk), had_k,
+                _C.ptr(output), _C.ptr(scaling), _C.ptr(sum_output), _C.dt(scaling), rows, cols, _C.stream())
