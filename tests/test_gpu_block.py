@@ -84,8 +84,9 @@ def test_kernel_mode_block_vs_simulation_oracle(dim, ffn, heads, grid, pad, lc):
 
     hb = WanAttentionBlockWithHipKernel.from_float(blk.to(DEV))
     xd = x.to(DEV).clone()
-    cq = WanAttentionBlockWithHipKernel._quant(ctx.to(DEV))
-    out = hb(xd, e0.to(DEV), ops.rope_table(freqs, grid, DEV), n_tok, cq)
+    from wan.quant_wanx_hip import _FpSrc
+
+    out = hb(xd, e0.to(DEV), ops.rope_table(freqs, grid, DEV), n_tok, _FpSrc(ctx.to(DEV), torch.bfloat16))
     assert out.data_ptr() == xd.data_ptr()  # residual stream updated in place
     got = out.float().cpu()[:n_tok]
 

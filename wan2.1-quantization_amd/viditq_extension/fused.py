@@ -160,6 +160,19 @@ def gate_residual_fuse(input, gate_msa, residual, out_dtype=None):
     return out
 
 
+def gate_residual_into_(residual, input, gate_msa):
+    """residual <- input * gate_msa[b] + residual, in place (fp32 stream, bf16/fp16 update)."""
+    rows, cols = _rows_cols("input", input)
+    _rows_cols("residual", residual)
+    _C.check_gpu("gate_msa", gate_msa)
+    _C.check_dtype("gate_msa", gate_msa, *_FP)
+    batch = gate_msa.shape[0]
+    with torch.cuda.device(input.device):
+        _C.call("wanq_gate_residual", _C.ptr(input), _C.dt(input), _C.ptr(gate_msa), _C.dt(gate_msa), gate_msa.stride(0),
+                _C.ptr(residual), _C.dt(residual), _C.ptr(residual), _C.dt(residual), rows, cols, rows // batch, _C.stream())
+    return residual
+
+
 # ---- calibration / PTQ reductions (no counterpart in the reference extension; they replace torch
 #      reductions in get_calib_data_wanx.py:262-263 and qdiff/base/base_quantizer.py:70-90)
 def col_absmax_(running_max, x):

@@ -23,7 +23,10 @@ from .modules.model import WanModel
 
 class HipLinearW8A8(nn.Module):
     """int8 weight [N,K] + per-output-channel fp32 (delta, zero_point) + fp32 bias.
-    weight_dequant = (code + zero_point) * delta  (StaticQuantizer.forward, qdiff/base/base_quantizer.py:56-59)."""
+    weight_dequant = (code + zero_point) * delta  (StaticQuantizer.forward, qdiff/base/base_quantizer.py:56-59).
+    Optional ViDiT activation transform: `act_premul` fp32 [K] (= channel_mask * rotation signs) and `rot`
+    (had_k, hadk) -- the producer kernel applies hadU(x * premul) before quantising this layer's input."""
+    quantized = True
 
     def __init__(self, in_features, out_features, bias=True, sym=False):
         super().__init__()
@@ -32,24 +35,18 @@ class HipLinearW8A8(nn.Module):
         self.register_buffer("scale_weight", torch.empty(out_features, dtype=torch.float32))
         self.register_buffer("zp_weight", None if sym else torch.empty(out_features, dtype=torch.float32))
         self.register_buffer("bias", torch.empty(out_features, dtype=torch.float32) if bias else None)
+        self.register_buffer("act_premul", None)
+        self.rot = None
 
     @staticmethod
     def quant_params(w, n_bits=8, sym=False):
-        """delta, zero_point of StaticQuantizer.init_quant_params (base_quantizer.py:70-90); the row statistics
-        come from the HIP reduction, the [N]-sized arithmetic is plain fp32 (IEEE: bit-identical to CPU torch)."""
-        lo, hi, am = fused.row_minmax(w)
-        # NB: on the GPU torch evaluates `tensor / python_scalar` as a multiply by the reciprocal (1 ulp off the
-        # IEEE quotient now and then); the golden vectors are IEEE divisions, so divide by a TENSOR.
-        if sym:
-            return am / torch.full_like(am, float(2 ** (n_bits - 1) - 1)), torch.zeros_like(am)
-        n_levels = 2 ** n_bits
-        hi, lo = hi.clamp_min(0.0), lo.clamp_max(0.0)
-        delta = (hi - lo) / torch.full_like(hi, float(n_levels - 1))
-        return delta, torch.round(lo / delta) + n_levels / 2
+        """delta, zero_point of StaticQuantizer.init_quant_params (base_quantizer.py:70-90)."""
+        from qdiff.base.base_quantizer import static_params
+
+        return static_params(w, n_bits, sym)
 
     @classmethod
     def from_float(cls, weight, bias=None, n_bits=8, sym=False, delta=None, zero_point=None):
-        assert n_bits == 8, "int8 storage: W4 goes through the packed path"
         weight = weight.detach().float().contiguous()
         m = cls(weight.shape[1], weight.shape[0], bias is not None, sym).to(weight.device)
         if delta is None:
@@ -64,10 +61,106 @@ class HipLinearW8A8(nn.Module):
             m.bias.copy_(bias.detach().float())
         return m
 
+    @classmethod
+    def from_quantized(cls, ql):
+        """From a qdiff QuantizedLinear (any variant): same integer codes, same parameters, same transform."""
+        wq = ql.w_quantizer
+        m = cls(ql.in_features, ql.out_features, ql.bias is not None, wq.sym).to(ql.int_weight.device)
+        m.weight.copy_(ql.int_weight)
+        m.scale_weight.copy_(wq.delta.reshape(-1).float())
+        if not wq.sym:
+            m.zp_weight.copy_(wq.zero_point.reshape(-1).float())
+        if ql.bias is not None:
+            m.bias.copy_(ql.bias.detach().float())
+        premul, rot = ql._act_transform()
+        m.act_premul, m.rot = premul, rot
+        return m
+
+    @property
+    def act_key(self):
+        """Layers with the same key can share one quantised copy of their input."""
+        return None if self.act_premul is None and self.rot is None else id(self)
+
     def forward(self, a_q, a_scale, a_sum, out_dtype=torch.bfloat16, gelu=False, gate=None, residual=None, out=None):
         return qgemm.w8a8_linear(a_q, self.weight, a_scale, self.scale_weight, self.bias,
                                  a_sum if self.zp_weight is not None else None, self.zp_weight, out_dtype=out_dtype,
                                  gelu=gelu, gate=gate, residual=residual, out=out)
+
+
+class HipLinearFp(nn.Module):
+    """A Linear the quant config leaves FP (remain_fp_regex): bf16 GEMM through torch (hipBLASLt), as the
+    reference's kernel-mode block keeps nn.Linear for those (quant_wanx_cuda.py:360,510)."""
+    quantized = False
+    act_key = "fp"
+
+    def __init__(self, weight, bias, dtype=torch.bfloat16):
+        super().__init__()
+        self.register_buffer("weight", weight.detach().to(dtype).contiguous())
+        self.register_buffer("bias", None if bias is None else bias.detach().to(dtype).contiguous())
+
+
+def _to_hip_linear(lin, n_bits, sym, act_dtype):
+    from qdiff.base.quant_layer import QuantizedLinear
+
+    if isinstance(lin, QuantizedLinear):
+        if lin.quant_mode and lin.w_quantizer is not None and lin.a_quantizer is not None:
+            return HipLinearW8A8.from_quantized(lin)
+        lin = lin.fp_module
+    if n_bits is None:
+        return HipLinearFp(lin.weight.data, lin.bias.data if lin.bias is not None else None, act_dtype)
+    return HipLinearW8A8.from_float(lin.weight.data, lin.bias.data if lin.bias is not None else None, n_bits, sym)
+
+
+class _LnSrc:
+    """Lazy activation = LayerNorm(x) (* gamma) * (1 + scale) + shift, materialised per consumer format."""
+
+    def __init__(self, blk, x, gamma, shift, scale):
+        self.blk, self.x, self.gamma, self.shift, self.scale, self.cache = blk, x, gamma, shift, scale, {}
+
+    def int8(self, lin):
+        key = lin.act_key
+        if key not in self.cache:
+            x, rows, C = self.x, self.x.shape[0], self.x.shape[1]
+            q = torch.empty(rows, C, dtype=torch.int8, device=x.device)
+            qs = torch.empty(2, rows, dtype=torch.float32, device=x.device)
+            if key is None:
+                fused.layernorm_nobias_t2i_quant_sum_fuse(q, x, self.gamma, self.shift, self.scale, qs[1], qs[0], self.blk.eps)
+            else:
+                fused.layernorm_rotate_quant(q, x, self.gamma, self.shift, self.scale, lin.act_premul, lin.rot, qs[1], qs[0], self.blk.eps)
+            self.cache[key] = (q, qs[0], qs[1])
+        return self.cache[key]
+
+    def fp(self):
+        if "fp" not in self.cache:
+            out = torch.empty(self.x.shape, dtype=self.blk.act_dtype, device=self.x.device)
+            fused.layernorm_nobias_t2i_fuse(out, self.x, self.gamma, self.shift, self.scale, self.blk.eps)
+            self.cache["fp"] = out
+        return self.cache["fp"]
+
+
+class _FpSrc:
+    """An activation that already exists in bf16 (attention output, GELU'd hidden, text context)."""
+
+    def __init__(self, t, fp_dtype=None):
+        self.t, self.cache, self.fp_dtype = t, {}, fp_dtype
+
+    def int8(self, lin):
+        key = lin.act_key
+        if key not in self.cache:
+            qs = torch.empty(2, self.t.shape[0], dtype=torch.float32, device=self.t.device)
+            if key is None:
+                q = fused.quant_sum(self.t, qs[1], qs[0])
+            else:
+                q = fused.rotate_quant(self.t, lin.act_premul, lin.rot, qs[1], qs[0])
+            self.cache[key] = (q, qs[0], qs[1])
+        return self.cache[key]
+
+    def fp(self):
+        if self.fp_dtype is not None and self.t.dtype != self.fp_dtype:
+            if "fp" not in self.cache:
+                self.cache["fp"] = self.t.to(self.fp_dtype)
+            return self.cache["fp"]
+        return self.t
 
 
 class _Attn(nn.Module):
@@ -92,30 +185,23 @@ class WanAttentionBlockWithHipKernel(nn.Module):
 
     @classmethod
     def from_float(cls, blk, n_bits=8, sym=False, act_dtype=torch.bfloat16):
-        """Build from an FP WanAttentionBlock (wan/modules/model.py)."""
+        """Build from a WanAttentionBlock (wan/modules/model.py) whose Linears are either plain nn.Linear
+        (quantized here with plain per-channel W8 when n_bits is given, kept FP when n_bits is None) or qdiff
+        QuantizedLinear variants (their codes / parameters / ViDiT transform are taken over as they are)."""
         m = cls(blk.dim, blk.ffn_dim, blk.num_heads, blk.eps, act_dtype).to(blk.modulation.device)
         for name in ("self_attn", "cross_attn"):
             src, dst = getattr(blk, name), getattr(m, name)
             for l in "qkvo":
-                lin = getattr(src, l)
-                setattr(dst, l, HipLinearW8A8.from_float(lin.weight.data, lin.bias.data if lin.bias is not None else None, n_bits, sym))
+                setattr(dst, l, _to_hip_linear(getattr(src, l), n_bits, sym, act_dtype))
             dst.norm_q_weight.copy_(src.norm_q.weight.data.float())
             dst.norm_k_weight.copy_(src.norm_k.weight.data.float())
-        m.ffn0 = HipLinearW8A8.from_float(blk.ffn[0].weight.data, blk.ffn[0].bias.data, n_bits, sym)
-        m.ffn2 = HipLinearW8A8.from_float(blk.ffn[2].weight.data, blk.ffn[2].bias.data, n_bits, sym)
+        m.ffn0 = _to_hip_linear(blk.ffn[0], n_bits, sym, act_dtype)
+        m.ffn2 = _to_hip_linear(blk.ffn[2], n_bits, sym, act_dtype)
         m.modulation.copy_(blk.modulation.data.float())
         if isinstance(blk.norm3, nn.LayerNorm) and blk.norm3.weight is not None:
             m.norm3_weight.copy_(blk.norm3.weight.data.float())
             m.norm3_bias.copy_(blk.norm3.bias.data.float())
         return m
-
-    # -- producers ---------------------------------------------------------------------------------
-    def _ln_quant(self, x, gamma, shift, scale):
-        rows = x.shape[0]
-        q = torch.empty(rows, self.dim, dtype=torch.int8, device=x.device)
-        qs = torch.empty(2, rows, dtype=torch.float32, device=x.device)
-        fused.layernorm_nobias_t2i_quant_sum_fuse(q, x, gamma, shift, scale, qs[1], qs[0], self.eps)
-        return q, qs[0], qs[1]
 
     @staticmethod
     def _quant(x):
@@ -123,52 +209,66 @@ class WanAttentionBlockWithHipKernel(nn.Module):
         q = fused.quant_sum(x, qs[1], qs[0])
         return q, qs[0], qs[1]
 
-    def forward(self, x, e0, rope, seq_len, ctx_q, sp=None):
+    def _linear(self, lin, src, out_dtype=None, gelu=False, gate=None, residual=None):
+        """y = lin(src) with the producer / epilogue fusion the layer's kind allows.  With `residual` (the fp32
+        stream) the result is residual + y*gate written in place."""
+        out_dtype = out_dtype or self.act_dtype
+        if lin.quantized:
+            q, s, ssum = src.int8(lin)
+            if residual is not None:
+                return lin(q, s, ssum, torch.float32, gate=gate, residual=residual, out=residual)
+            return lin(q, s, ssum, out_dtype, gelu=gelu)
+        y = torch.nn.functional.linear(src.fp(), lin.weight, lin.bias)
+        if gelu:
+            y = torch.nn.functional.gelu(y, approximate="tanh")
+        if residual is not None:
+            fused.gate_residual_into_(residual, y, gate.view(1, -1))
+            return residual
+        return y
+
+    def forward(self, x, e0, rope, seq_len, ctx, sp=None):
         """x: fp32 [L, C] residual stream (this rank's token shard under sequence parallelism), updated IN PLACE.
         e0: fp32 [1, 6, C].  rope: fp32 [pos, d/2, 2] for the local tokens.  seq_len: number of real (unpadded)
-        tokens of the WHOLE sequence.  ctx_q: (int8 [Lc, C], scale [Lc], sum [Lc]) text context.
-        sp: wan.distributed.SeqParallel or None."""
-        H, d, dt = self.num_heads, self.head_dim, self.act_dtype
+        tokens of the WHOLE sequence.  ctx: _FpSrc of the bf16 text context [Lc, C] (shared by all blocks so that
+        its plain int8 copy is made once per pass).  sp: wan.distributed.SeqParallel or None."""
+        H, d = self.num_heads, self.head_dim
         e = self.modulation + e0  # [1, 6, C] fp32
         sa, ca = self.self_attn, self.cross_attn
 
-        # ---- self attention: LN*(1+e1)+e0 -> int8 -> q,k,v GEMMs -> RMSNorm+RoPE -> attention -> int8 -> o GEMM (+gate, +res)
-        hq, hs, hsum = self._ln_quant(x, None, e[:, 0], e[:, 1])
-        q = sa.q(hq, hs, hsum, dt)
+        # ---- self attention: LN*(1+e1)+e0 -> q,k,v -> RMSNorm+RoPE -> attention -> o (+gate, +residual)
+        h = _LnSrc(self, x, None, e[:, 0], e[:, 1])
+        q = self._linear(sa.q, h)
         ops.rmsnorm_rope_(q, sa.norm_q_weight, rope, d, eps=self.eps)
         if sp is None or sp.size == 1:
-            k = sa.k(hq, hs, hsum, dt)
+            k = self._linear(sa.k, h)
             ops.rmsnorm_rope_(k, sa.norm_k_weight, rope, d, eps=self.eps)
-            v = sa.v(hq, hs, hsum, dt)
+            v = self._linear(sa.v, h)
             o = ops.attention(q, k, v, H, seq_len)
         else:  # Ulysses: the q / k all-to-alls fly under the k / v GEMMs
             wq = sp.scatter_heads(q, async_op=True)
-            k = sa.k(hq, hs, hsum, dt)
+            k = self._linear(sa.k, h)
             ops.rmsnorm_rope_(k, sa.norm_k_weight, rope, d, eps=self.eps)
             wk = sp.scatter_heads(k, async_op=True)
-            v = sa.v(hq, hs, hsum, dt)
+            v = self._linear(sa.v, h)
             wv = sp.scatter_heads(v, async_op=True)
             o = ops.attention(wq.wait(), wk.wait(), wv.wait(), H // sp.size, seq_len)
             o = sp.gather_heads(o)
-        oq, os_, osum = self._quant(o)
-        sa.o(oq, os_, osum, torch.float32, gate=e[0, 2].contiguous(), residual=x, out=x)
+        self._linear(sa.o, _FpSrc(o), gate=e[0, 2].contiguous(), residual=x)
 
-        # ---- cross attention: LN_affine -> int8 -> q GEMM; k,v from the (pre-quantized) text context
-        hq, hs, hsum = self._ln_quant(x, self.norm3_weight, self.norm3_bias.view(1, -1), None)
-        q = ca.q(hq, hs, hsum, dt)
+        # ---- cross attention: LN_affine -> q; k,v from the text context
+        h = _LnSrc(self, x, self.norm3_weight, self.norm3_bias.view(1, -1), None)
+        q = self._linear(ca.q, h)
         ops.rmsnorm_rope_(q, ca.norm_q_weight, None, d, eps=self.eps)
-        k = ca.k(*ctx_q, dt)
+        k = self._linear(ca.k, ctx)
         ops.rmsnorm_rope_(k, ca.norm_k_weight, None, d, eps=self.eps)
-        v = ca.v(*ctx_q, dt)
+        v = self._linear(ca.v, ctx)
         o = ops.attention(q, k, v, H)
-        oq, os_, osum = self._quant(o)
-        ca.o(oq, os_, osum, torch.float32, gate=self.ones_gate, residual=x, out=x)
+        self._linear(ca.o, _FpSrc(o), gate=self.ones_gate, residual=x)
 
-        # ---- FFN: LN*(1+e4)+e3 -> int8 -> GEMM+GELU -> int8 -> GEMM (+gate, +res)
-        hq, hs, hsum = self._ln_quant(x, None, e[:, 3], e[:, 4])
-        h = self.ffn0(hq, hs, hsum, dt, gelu=True)
-        hq, hs, hsum = self._quant(h)
-        self.ffn2(hq, hs, hsum, torch.float32, gate=e[0, 5].contiguous(), residual=x, out=x)
+        # ---- FFN: LN*(1+e4)+e3 -> GEMM+GELU -> GEMM (+gate, +residual)
+        h = _LnSrc(self, x, None, e[:, 3], e[:, 4])
+        hid = self._linear(self.ffn0, h, gelu=True)
+        self._linear(self.ffn2, _FpSrc(hid), gate=e[0, 5].contiguous(), residual=x)
         return x
 
 
@@ -212,7 +312,7 @@ class QuantWanModelHip(nn.Module):
                 h = sp.shard_rows(h)
                 rope = rope[sp.rank * lp:(sp.rank + 1) * lp]  # may be shorter than lp on the last rank: pads stay unrotated
             h = h.contiguous()
-            cq = WanAttentionBlockWithHipKernel._quant(ctx[0].float().contiguous())
+            cq = _FpSrc(ctx[0].float().contiguous(), self.blocks[0].act_dtype)
             for blk in self.blocks:
                 blk(h, e0.float(), rope, seq_lens[0], cq, sp)
             out = self.fp.head(h.unsqueeze(0), e)
