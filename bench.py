@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--guide", type=float, default=5.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quality", action="store_true")
+    ap.add_argument("--quant-config", dest="quant_config", default="w8a8_all_linears.yaml", help="file under quant_configs/")
     ap.add_argument("--no-cfg-parallel", action="store_true", help="pure Ulysses over all GPUs (needs heads %% N == 0)")
     args = ap.parse_args()
 
@@ -139,7 +140,6 @@ def main():
     from viditq_extension import qgemm
     from wan.configs import SIZE_CONFIGS, WAN_CONFIGS, latent_shape, seq_len_for
     from wan.distributed.parallel import ParallelPlan
-    from wan.quant_wanx_hip import QuantWanModelHip
     from wan.utils.fm_solvers import FlowMatchScheduler
 
     cfg = WAN_CONFIGS[args.model]
@@ -149,9 +149,6 @@ def main():
     seq_len = seq_len_for(shape, sp_size=plan.sp_degree)
     torch.backends.cuda.matmul.allow_tf32 = False
 
-    fp = synth_model(args.model, dev, seed=0)
-    model = QuantWanModelHip(fp, n_bits=8, sym=False, keep_fp_blocks=(world == 1 and not args.no_quality))
-
     g = torch.Generator(device=dev).manual_seed(42)
     latent0 = torch.randn(shape, generator=g, device=dev)
     ctx_c = torch.randn(512, cfg["text_dim"], generator=g, device=dev) * 0.1
@@ -159,6 +156,34 @@ def main():
     total = args.steps + args.warmup
     sched = FlowMatchScheduler(cfg["num_train_timesteps"], shift=1.0)
     sched.set_timesteps(max(total, 30), device=dev, shift=5.0)
+
+    # ---- the reference's flow on the synthetic model: FP model -> quant_layer_refactor (config) -> calibration pass
+    #      (per-channel absmax hooks) -> channel masks + rotations (ptq) -> kernel mode (quant_generate, if_hardware)
+    from qdiff import config as qcfg
+    from qdiff.base.quant_layer import QuantizedLinear
+    from wan import calib
+    from wan.quant_wanx import QuantWanModel
+
+    quant_config = qcfg.load(os.path.join(ROOT, "wan2.1-quantization_amd", "quant_configs", args.quant_config))
+    fp = synth_model(args.model, dev, seed=0)
+    model = QuantWanModel.from_float(fp, quant_config)
+    model.quant_layer_refactor()
+    hooks = calib.add_hooks(fp)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        fp([latent0], sched.timesteps[0:1], [ctx_c], seq_len_for(shape))
+    calib_data = calib.gather_and_save_activation(hooks)
+    gen = torch.Generator().manual_seed(0)
+    n_vidit = 0
+    for name, mod in model.named_modules():
+        if isinstance(mod, QuantizedLinear) and (mod.uses_mask or mod.uses_rotation):
+            calib.init_rotation_and_channel_mask_(mod, name, calib_data, gen)
+            n_vidit += 1
+    model.set_init_done()
+    model.hardware_forward_refactor()
+    n_quant = sum(1 for m in model.modules() if isinstance(m, QuantizedLinear))
+    if world > 1 or args.no_quality:
+        del fp
+        torch.cuda.empty_cache()
 
     def step(latent, i):
         t = sched.timesteps[i:i + 1]
@@ -198,9 +223,10 @@ def main():
         "metric": "denoising steps/sec Wan2.1-1.3B W8A8 832x480x81f", "value": args.steps / dt, "unit": "steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
-        "config": {"workload": f"Wan2.1-{args.model} DiT, W8A8 all block linears (W asym per-channel static, A sym per-token dynamic), "
+        "config": {"workload": f"Wan2.1-{args.model} DiT, {n_quant} Linears W8A8 (W asym per-channel static, A sym per-token dynamic; "
+                               f"ViDiT-Q scale+rotate alpha=0.5665 on {n_vidit} self-attn q/k/v layers), "
                                f"{args.size}x{args.frames}f, latent {list(shape)}, L={seq_len}, cond+uncond+CFG+scheduler per step",
-                   "attention": "bf16", "parallelism": plan.describe()},
+                   "quant_config": args.quant_config, "attention": "bf16", "parallelism": plan.describe()},
     }
     if gs:
         ach = gs["ops"] / gs["seconds"]
@@ -213,9 +239,8 @@ def main():
         t = sched.timesteps[0:1]
         with torch.no_grad():
             yq = model([latent0], t, [ctx_c], seq_len_for(shape))[0]
-            model.fp.blocks = model.fp_blocks
             with torch.autocast("cuda", dtype=torch.bfloat16):
-                yf = model.fp([latent0], t, [ctx_c], seq_len_for(shape))[0]
+                yf = fp([latent0], t, [ctx_c], seq_len_for(shape))[0]
         mse = (yq - yf).pow(2).mean().item()
         rng = (yf.max() - yf.min()).item()
         out["quality"] = {"tensor": "DiT output latent (noise_pred)", "rel_l2_vs_fp": ((yq - yf).norm() / yf.norm()).item(),
