@@ -113,7 +113,12 @@ __device__ __forceinline__ void hadamard_rows(float (&v)[NCH][8], const bool (&o
       const bool up = (lane & bit) != 0;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float o = __shfl_xor(v[i][j], bit, 64);
+        // lane ^ bit inside a group of 32 lanes: ds_swizzle bit mode (and 0x1f, or 0, xor bit) -- no address VGPR
+        float o;
+        if (bit == 1) o = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v[i][j]), (1 << 10) | 0x1f));
+        else if (bit == 2) o = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v[i][j]), (2 << 10) | 0x1f));
+        else if (bit == 4) o = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v[i][j]), (4 << 10) | 0x1f));
+        else o = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v[i][j]), (8 << 10) | 0x1f));
         v[i][j] = up ? o - v[i][j] : v[i][j] + o;
       }
     }
@@ -141,6 +146,7 @@ __device__ __forceinline__ void hadamard_rows(float (&v)[NCH][8], const bool (&o
       const float* hrow = hk_lds + (chunk >> 4) * K;
       const float* src = rowbuf + (chunk & 15) * 8;
       float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
       for (int k2 = 0; k2 < K; ++k2) {
         const float sgn = hrow[k2];
         const float4 a = *reinterpret_cast<const float4*>(src + k2 * 128);
@@ -272,15 +278,11 @@ __global__ __launch_bounds__(256) void rowwise_kernel(const RowParams p) {
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     int qi[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      qi[j] = quant_div_rne(v[i][j], scale, inv);
-      isum += qi[j];
-    }
-    if (ok[i]) {
-      const uint2 pk = make_uint2(pack4_i8(qi[0], qi[1], qi[2], qi[3]), pack4_i8(qi[4], qi[5], qi[6], qi[7]));
-      *reinterpret_cast<uint2*>(p.q + rbase + (sub * 64 + lane + i * 64 * WPR) * 8) = pk;
-    }
+    quant8_div_rne(v[i], scale, inv, qi);
+    const uint32_t lo = pack4_i8_fast(qi[0], qi[1], qi[2], qi[3]), hi = pack4_i8_fast(qi[4], qi[5], qi[6], qi[7]);
+    isum = __builtin_amdgcn_sdot4((int)lo, 0x01010101, isum, false);  // sum of the four signed bytes
+    isum = __builtin_amdgcn_sdot4((int)hi, 0x01010101, isum, false);
+    if (ok[i]) *reinterpret_cast<uint2*>(p.q + rbase + (sub * 64 + lane + i * 64 * WPR) * 8) = make_uint2(lo, hi);
   }
   if (p.sum) {
     const int tot = red.isum(isum, 3);

@@ -144,15 +144,39 @@ __device__ __forceinline__ float gelu_tanh_f32(float x) {
   return 0.5f * x * (1.0f + tanhf(inner));
 }
 
-// q = clamp(rne(x / s)) with IEEE fp32 division semantics, computed as a multiply by 1/s plus an exact
-// fallback: the product t = x*inv is within 1.8e-7*|t| of fl(x/s); only when t sits that close to a
-// .5 boundary can rint(t) differ from rint(fl(x/s)), and then the true division is evaluated.
+// q = clamp(rne(x / s)) with IEEE fp32 division semantics at multiply cost.  t = x*inv is within 1.8e-7*|t| of
+// fl(x/s); rint(t) can differ from rint(fl(x/s)) only when t sits that close to a .5 boundary, and then the true
+// division is evaluated (rare: ~1e-5 of the elements).  Eight elements at a time so that the fallback costs one
+// wave-level branch per chunk: per element the common path is mul, rndne, sub, fma, cmp, med3, cvt.
+__device__ __forceinline__ void quant8_div_rne(const float (&x)[8], float s, float inv, int (&q)[8]) {
+  float r[8];
+  bool near = false;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float t = x[j] * inv;
+    r[j] = rintf(t);
+    near |= fabsf(t - r[j]) >= fmaf(-4e-7f, fabsf(t), 0.5f);
+  }
+  if (near) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = rintf(x[j] / s);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) q[j] = (int)__builtin_amdgcn_fmed3f(r[j], -128.f, 127.f);
+}
+
+// 4 ints in [-128,127] -> packed bytes: two saturating i32->i16 packs + one byte permute
+__device__ __forceinline__ uint32_t pack4_i8_fast(int a, int b, int c, int d) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const s16x2 lo = __builtin_amdgcn_cvt_pk_i16(a, b), hi = __builtin_amdgcn_cvt_pk_i16(c, d);
+  return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x06040200u);
+}
+
 __device__ __forceinline__ int quant_div_rne(float x, float s, float inv) {
   float t = x * inv;
-  const float fr = fabsf(t - truncf(t));
-  if (fabsf(fr - 0.5f) <= 4e-7f * fabsf(t) + 1e-30f) t = x / s;
-  const float r = rintf(t);
-  return (int)fminf(fmaxf(r, -128.f), 127.f);
+  float r = rintf(t);
+  if (fabsf(t - r) >= fmaf(-4e-7f, fabsf(t), 0.5f)) r = rintf(x / s);
+  return (int)__builtin_amdgcn_fmed3f(r, -128.f, 127.f);
 }
 
 __device__ __forceinline__ uint32_t pack4_i8(int a, int b, int c, int d) {
