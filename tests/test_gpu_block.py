@@ -62,7 +62,8 @@ def make_block(dim, ffn, heads, seed):
     return blk
 
 
-@pytest.mark.parametrize("dim,ffn,heads,grid,pad,lc", [(256, 512, 2, (3, 6, 10), 4, 40), (1536, 8960, 12, (2, 6, 8), 0, 64)])
+@pytest.mark.parametrize("dim,ffn,heads,grid,pad,lc", [(256, 512, 2, (3, 6, 10), 4, 40), (1536, 8960, 12, (2, 6, 8), 0, 64),
+                                                   (5120, 13824, 40, (1, 6, 8), 0, 32)])  # last: the 14B block shapes
 def test_kernel_mode_block_vs_simulation_oracle(dim, ffn, heads, grid, pad, lc):
     from wan import ops
     from wan.quant_wanx_hip import WanAttentionBlockWithHipKernel
@@ -142,3 +143,58 @@ def test_flash_attention_strided_views_of_packed_qkv():
     out = ops.attention(q, k, v, H)
     ref = ops.attention(q.contiguous(), k.contiguous(), v.contiguous(), H)
     assert torch.equal(out, ref)
+
+
+def test_kernel_mode_block_with_vidit_and_fp_layers_vs_oracle():
+    """The reference's shipped configuration on one real-size block: ViDiT-Q (channel mask x Hadamard rotation)
+    W8A8 on self_attn q/k/v, every other Linear left FP (remain_fp_regex) -- kernel-mode block vs the simulation
+    oracle with the same masks and the same rotation signs."""
+    from oracle import qdiff_ref as qr
+    from qdiff import config as qcfg
+    from qdiff.base.quant_model import quant_layer_refactor_
+    from qdiff.utils import apply_func_to_submodules
+    from wan import calib, ops
+    from wan.quant_wanx_hip import WanAttentionBlockWithHipKernel, _FpSrc
+
+    dim, ffn, heads, grid, lc = 1536, 8960, 12, (2, 6, 8), 64
+    blk = make_block(dim, ffn, heads, 3)
+    sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    n_tok = grid[0] * grid[1] * grid[2]
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(n_tok, dim, generator=g)
+    x[:, 9] *= 15.0
+    e0 = torch.randn(1, 6, dim, generator=g) * 0.3
+    ctx = torch.randn(lc, dim, generator=g)
+    freqs = wr.rope_freqs(dim // heads)
+    act_mask = (torch.rand(dim, generator=g) * 3 + 0.2)
+
+    cfg = qcfg.create({"weight": {"n_bits": 8, "sym": False}, "act": {"n_bits": 8, "sym": True},
+                       "viditq": {"alpha": 0.5665, "layer_name_regex": ""},
+                       "remain_fp_regex": r"self_attn\.(?!q$)(?!k$)(?!v$)[^.]+|ffn.*|cross_attn"})
+    blk = blk.to(DEV)
+    apply_func_to_submodules(blk, torch.nn.Linear, quant_layer_refactor_, name=None, parent_module=None, quant_config=cfg,
+                             full_name=None, remain_fp_regex=cfg.remain_fp_regex)
+    gen = torch.Generator().manual_seed(11)
+    vidit = {}
+    for name in ("q", "k", "v"):
+        lin = getattr(blk.self_attn, name)
+        assert type(lin).__name__ == "ViDiTQuantizedLinear"
+        calib.init_rotation_and_channel_mask_(lin, "x", {"x": act_mask[None]}, gen)
+        R = torch.from_numpy(qr.hadamard_from_signs(lin.rotation_signs.numpy()))
+        vidit["self_attn." + name] = (lin.channel_mask.cpu(), R)
+    assert type(blk.self_attn.o).__name__ == "Linear" and type(blk.ffn[0]).__name__ == "Linear"
+
+    # oracle: fake-quant ViDiT on q/k/v, FP elsewhere
+    lin = {}
+    for nm in wr.LINEARS:
+        w, b = sd[nm + ".weight"], sd[nm + ".bias"]
+        lin[nm] = wr.FakeQuantLinear(w, b, 8, 8, False, *vidit[nm]) if nm in vidit else wr.FpLinear(w, b)
+    norm_w = {k: sd[k + ".weight"].float() for k in ("self_attn.norm_q", "self_attn.norm_k", "cross_attn.norm_q", "cross_attn.norm_k")}
+    ref = wr.BlockRef(lin, norm_w, sd["modulation"], heads, 1e-6, (sd["norm3.weight"].float(), sd["norm3.bias"].float()))(x, e0, grid, n_tok, ctx, freqs)
+
+    hb = WanAttentionBlockWithHipKernel.from_float(blk, None)
+    assert hb.self_attn.q.quantized and hb.self_attn.q.rot[0] == 12 and not hb.self_attn.o.quantized and not hb.ffn0.quantized
+    out = hb(x.to(DEV).clone(), e0.to(DEV), ops.rope_table(freqs, grid, DEV), n_tok, _FpSrc(ctx.to(DEV), torch.bfloat16))
+    err = rel_err(out.float().cpu(), ref)
+    print(f"shipped-config block (ViDiT q/k/v + FP rest): rel err vs oracle {err:.2e}")
+    assert err < 1e-2

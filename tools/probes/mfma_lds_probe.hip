@@ -30,7 +30,7 @@ __global__ __launch_bounds__(512, 2) void probe(int* out, long long* cyc, int ni
   long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < nit; ++it) {
     const char* st = smem + (it & 1) * 65536;
-    if (MODE >= 4) {  // 8 LDS-DMA instructions per wave per K-tile into the OTHER stage (here: a scratch region), one tile ahead
+    if (MODE == 4 || MODE == 5) {  // 8 LDS-DMA instructions per wave per K-tile into the OTHER stage (here: a scratch region), one tile ahead
       char* dst = smem + 131072 + wave * 1024;
       _Pragma("unroll") for (int q = 0; q < 8; ++q)
         __builtin_amdgcn_global_load_lds((glb_void*)(gsrc + (((size_t)blockIdx.x * 65536 + (size_t)(it * 8 + q) * 8192) % gspan)), (lds_void*)(dst + (q & 1) * 8192), 16, 0, 0);
@@ -39,6 +39,20 @@ __global__ __launch_bounds__(512, 2) void probe(int* out, long long* cyc, int ni
     if (MODE == 1 || MODE == 5) { if (MODE == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); MM(wf0, xf0) MM(wf0, xf0) MM(wf0, xf0) MM(wf0, xf0) }
     else if (MODE == 3) {
       FR(wf0, xf0, st, 0) MM(wf0, xf0) FR(wf0, xf0, st, 1) MM(wf0, xf0) FR(wf0, xf0, st, 2) MM(wf0, xf0) FR(wf0, xf0, st, 3) MM(wf0, xf0)
+    } else if (MODE == 6 || MODE == 8) {
+      char* dst = smem + 131072 + wave * 1024;
+#define DMA2(q0) { _Pragma("unroll") for (int q = q0; q < q0 + 2; ++q) __builtin_amdgcn_global_load_lds((glb_void*)(gsrc + (((size_t)blockIdx.x * 65536 + (size_t)(it * 8 + q) * 8192) % gspan)), (lds_void*)(dst + (q & 1) * 8192), 16, 0, 0); }
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      FR(wf1, xf1, st, 1) DMA2(0) __builtin_amdgcn_sched_barrier(0); if (MODE == 8) __builtin_amdgcn_s_setprio(1); MM(wf0, xf0) if (MODE == 8) __builtin_amdgcn_s_setprio(0);
+      FR(wf0, xf0, st, 2) DMA2(2) __builtin_amdgcn_sched_barrier(0); if (MODE == 8) __builtin_amdgcn_s_setprio(1); MM(wf1, xf1) if (MODE == 8) __builtin_amdgcn_s_setprio(0);
+      FR(wf1, xf1, st, 3) DMA2(4) __builtin_amdgcn_sched_barrier(0); if (MODE == 8) __builtin_amdgcn_s_setprio(1); MM(wf0, xf0) if (MODE == 8) __builtin_amdgcn_s_setprio(0);
+      FR(wf0, xf0, smem + ((it + 1) & 1) * 65536, 0) DMA2(6) __builtin_amdgcn_sched_barrier(0); if (MODE == 8) __builtin_amdgcn_s_setprio(1); MM(wf1, xf1) if (MODE == 8) __builtin_amdgcn_s_setprio(0);
+    } else if (MODE == 7) {
+      if (wave < 4) { char* dst = smem + 131072 + wave * 1024; _Pragma("unroll") for (int q = 0; q < 16; ++q) __builtin_amdgcn_global_load_lds((glb_void*)(gsrc + (((size_t)blockIdx.x * 65536 + (size_t)(it * 16 + q) * 4096) % gspan)), (lds_void*)(dst + (q & 3) * 4096), 16, 0, 0); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+      FR(wf1, xf1, st, 1) __builtin_amdgcn_sched_barrier(0); MM(wf0, xf0)
+      FR(wf0, xf0, st, 2) __builtin_amdgcn_sched_barrier(0); MM(wf1, xf1)
+      FR(wf1, xf1, st, 3) __builtin_amdgcn_sched_barrier(0); MM(wf0, xf0)
+      FR(wf0, xf0, smem + ((it + 1) & 1) * 65536, 0) __builtin_amdgcn_sched_barrier(0); MM(wf1, xf1)
     } else {
       FR(wf1, xf1, st, 1) __builtin_amdgcn_sched_barrier(0); MM(wf0, xf0)
       FR(wf0, xf0, st, 2) __builtin_amdgcn_sched_barrier(0); MM(wf1, xf1)
@@ -69,6 +83,9 @@ int main() {
   RUN(3, 512, "reads right before use, 2 waves/SIMD")
   RUN(4, 512, "reads || mfma + 8 LDS-DMA/wave/tile (64 MB span)")
   RUN(5, 512, "mfma only + 8 LDS-DMA/wave/tile")
+  RUN(6, 512, "DMA spread 2 per k-step")
+  RUN(8, 512, "DMA spread 2 per k-step + setprio(1) on MFMA")
+  RUN(7, 512, "DMA by waves 0..3 only (16 each)")
   RUN(0, 256, "reads(s+1) || mfma(s), 1 wave/SIMD")
   RUN(1, 256, "mfma only, 1 wave/SIMD")
   RUN(2, 256, "reads only, 1 wave/SIMD")
