@@ -158,6 +158,16 @@ int wanq_layernorm_rotate_quant_rows(const void* x, int x_dtype, const void* gam
                                      float eps, const float* premul, const float* hadk, int had_k, int8_t* q,
                                      void* scale, void* sum, int vec_dtype, int64_t rows, int cols, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * 4-bit weight storage.  packed[r, j] = (q[r,2j] + bias) | (q[r,2j+1] + bias) << 4, bias 8 for signed codes in
+ * [-8,7] (qdiff 4-bit asym, base_quantizer.py:32,89-90), bias 0 for unsigned codes 0..15 (QServe convention,
+ * ViDiT-Q/kernels/csrc/qgemm/w4a8/w4a8_per_channel_gemm_cuda_qserve.cu:287-299).  cols % 16 == 0.
+ * The reference exports a W4A8 GEMM (w4a8_of16_nobias_weight_asym_qserve) but ships neither a packer nor a
+ * module that calls it; here W4 is a storage format: codes are expanded to int8 (wanq_unpack_w4) and run on
+ * wanq_gemm_w8a8, whose asymmetric epilogue with zp = -zero covers  y = acc*sW*sA - (sW*zW)*sumA. */
+int wanq_pack_w4(const int8_t* q, uint8_t* packed, int bias, int64_t rows, int cols, void* stream);
+int wanq_unpack_w4(const uint8_t* packed, int8_t* q, int bias, int64_t rows, int cols, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

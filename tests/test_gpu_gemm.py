@@ -131,3 +131,28 @@ def test_shape_errors_raise_runtime_error():
         qgemm().w8a8_o32(a, w)
     with pytest.raises(RuntimeError, match="shape"):
         qgemm().w8a8_o32(torch.zeros(8, 32, dtype=torch.int8, device=DEV), w)
+
+
+def test_w4_pack_unpack_roundtrip_and_w4a8_equation():
+    """4-bit codes survive pack/unpack exactly; the QServe W4A8 entry point reproduces its equation
+    (oracle/kernel_ref.py::w4a8_of16, K/csrc/qgemm/w4a8/w4a8_per_channel_gemm_cuda_qserve.cu:580-587)."""
+    rng = np.random.default_rng(44)
+    N, K, M = 136, 256, 77
+    q = rng.integers(-8, 8, size=(N, K), dtype=np.int8)
+    packed = qgemm().pack_w4(t(q), bias=8)
+    assert packed.shape == (N, K // 2) and packed.dtype == torch.uint8
+    ref = ((q[:, 0::2].astype(np.int32) + 8) | ((q[:, 1::2].astype(np.int32) + 8) << 4)).astype(np.uint8)
+    assert np.array_equal(packed.cpu().numpy(), ref)
+    assert np.array_equal(qgemm().unpack_w4(packed, bias=8).cpu().numpy(), q)
+
+    u4 = rng.integers(0, 16, size=(N, K), dtype=np.int8)
+    a = rng.integers(-127, 128, size=(M, K), dtype=np.int8)
+    ws = rng.uniform(0.01, 0.03, N).astype(np.float16)
+    zw = rng.integers(0, 16, N).astype(np.float32)
+    w_sz = (ws.astype(np.float32) * zw).astype(np.float16)
+    asc = rng.uniform(0.005, 0.02, M).astype(np.float16)
+    a_ssum = (a.sum(1) * asc.astype(np.float32)).astype(np.float16)
+    out = torch.zeros(M, N, dtype=torch.float16, device=DEV)
+    qgemm().w4a8_of16_nobias_weight_asym_qserve(t(a), qgemm().pack_w4(t(u4), bias=0), t(ws), t(asc), t(w_sz), t(a_ssum), out)
+    refy = kr.w4a8_of16(a, u4, ws, asc, w_sz, a_ssum)
+    np.testing.assert_allclose(out.float().cpu().numpy(), refy, rtol=4e-3, atol=4e-2)

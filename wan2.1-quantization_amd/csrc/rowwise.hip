@@ -616,3 +616,58 @@ extern "C" int wanq_layernorm_rotate_quant_rows(const void* x, int x_dtype, cons
   p.premul = premul; p.hadk = hadk; p.had_k = had_k; p.had_div = sqrtf((float)cols);
   return launch_rowwise<true>(p, (hipStream_t)stream, "wanq_layernorm_rotate_quant_rows");
 }
+
+// ------------------------------------------------------------------------------ 4-bit weight storage
+// Packed layout (ours; the reference ships no packer and its QServe layout is an NVIDIA ldmatrix interleave):
+// row-major [N, K/2] bytes, byte j of a row = code[2j] | code[2j+1] << 4 with codes biased to unsigned 0..15.
+// Weights are a few MB per layer against hundreds of MB of activations, so W4 is a STORAGE format here: a
+// layer's codes are expanded to int8 once per call (or once at load) and run on the int8 MFMA kernel.
+__global__ __launch_bounds__(256) void pack_w4_kernel(const int8_t* q, uint8_t* packed, int bias, int64_t total16) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total16; i += (int64_t)gridDim.x * 256) {
+    const uint4 v = *reinterpret_cast<const uint4*>(q + i * 16);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o[2] = {0, 0};
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      const int c = (int)(int8_t)((w[b >> 2] >> (8 * (b & 3))) & 0xff) + bias;
+      o[b >> 3] |= (uint32_t)(c & 0xf) << (4 * (b & 7));
+    }
+    *reinterpret_cast<uint2*>(packed + i * 8) = make_uint2(o[0], o[1]);
+  }
+}
+
+__global__ __launch_bounds__(256) void unpack_w4_kernel(const uint8_t* packed, int8_t* q, int bias, int64_t total16) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total16; i += (int64_t)gridDim.x * 256) {
+    const uint2 v = *reinterpret_cast<const uint2*>(packed + i * 8);
+    const uint32_t w[2] = {v.x, v.y};
+    uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      const int c = (int)((w[b >> 3] >> (4 * (b & 7))) & 0xf) - bias;
+      o[b >> 2] |= (uint32_t)(c & 0xff) << (8 * (b & 3));
+    }
+    *reinterpret_cast<uint4*>(q + i * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+extern "C" int wanq_pack_w4(const int8_t* q, uint8_t* packed, int bias, int64_t rows, int cols, void* stream) {
+  WANQ_REQUIRE(q && packed, WANQ_E_ARG, "wanq_pack_w4: NULL pointer");
+  WANQ_REQUIRE(cols >= 16 && cols % 16 == 0, WANQ_E_SHAPE, "wanq_pack_w4: cols=%d must be a multiple of 16", cols);
+  WANQ_REQUIRE(rows >= 0 && bias >= 0 && bias <= 8, WANQ_E_ARG, "wanq_pack_w4: bad rows / bias");
+  const int64_t total16 = rows * (cols / 16);
+  if (total16 == 0) return WANQ_OK;
+  const unsigned grid = (unsigned)((total16 + 255) / 256 < 4096 ? (total16 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_w4_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, q, packed, bias, total16);
+  return check_launch("wanq_pack_w4");
+}
+
+extern "C" int wanq_unpack_w4(const uint8_t* packed, int8_t* q, int bias, int64_t rows, int cols, void* stream) {
+  WANQ_REQUIRE(q && packed, WANQ_E_ARG, "wanq_unpack_w4: NULL pointer");
+  WANQ_REQUIRE(cols >= 16 && cols % 16 == 0, WANQ_E_SHAPE, "wanq_unpack_w4: cols=%d must be a multiple of 16", cols);
+  WANQ_REQUIRE(rows >= 0 && bias >= 0 && bias <= 8, WANQ_E_ARG, "wanq_unpack_w4: bad rows / bias");
+  const int64_t total16 = rows * (cols / 16);
+  if (total16 == 0) return WANQ_OK;
+  const unsigned grid = (unsigned)((total16 + 255) / 256 < 4096 ? (total16 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(unpack_w4_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, packed, q, bias, total16);
+  return check_launch("wanq_unpack_w4");
+}

@@ -37,6 +37,8 @@ PROTOTYPES = {
     "wanq_rmsnorm_rope": [_vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _i64, _i64, _f, _vp],
     "wanq_rotate_quant_rows": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _vp],
     "wanq_layernorm_rotate_quant_rows": [_vp, _i, _vp, _vp, _vp, _i, _i64, _i64, _f, _vp, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _vp],
+    "wanq_pack_w4": [_vp, _vp, _i, _i64, _i, _vp],
+    "wanq_unpack_w4": [_vp, _vp, _i, _i64, _i, _vp],
     "wanq_attention_fwd": [_vp, _vp, _vp, _vp, _i, _i64, _i64, _i, _i, _i64, _i64, _i64, _i64, _f, _vp],
 }
 for _name, _args in PROTOTYPES.items():

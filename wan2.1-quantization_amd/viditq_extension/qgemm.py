@@ -122,3 +122,38 @@ def w8a8_o32(input, weight):
         _C.call("wanq_gemm_w8a8", _C.ptr(input), _C.ptr(weight), _C.ptr(out), _C.I32, None, None, _C.F32, None, None,
                 _C.F32, None, _C.F32, None, None, 0, M, N, K, _C.stream())
     return out
+
+
+# ---- W4 storage -------------------------------------------------------------------------------------------------
+def pack_w4(codes, bias=8):
+    """int8 codes [N, K] (signed [-8,7] with bias 8, or unsigned 0..15 with bias 0) -> uint8 [N, K/2]."""
+    _check_i8("codes", codes)
+    N, K = codes.shape
+    out = torch.empty((N, K // 2), dtype=torch.uint8, device=codes.device)
+    with torch.cuda.device(codes.device):
+        _C.call("wanq_pack_w4", _C.ptr(codes), _C.ptr(out), int(bias), N, K, _C.stream())
+    return out
+
+
+def unpack_w4(packed, bias=8):
+    """uint8 [N, K/2] -> int8 codes [N, K]."""
+    _C.check_gpu("packed", packed)
+    _C.check_contig("packed", packed)
+    _C.check_dtype("packed", packed, torch.uint8)
+    N, K2 = packed.shape
+    out = torch.empty((N, K2 * 2), dtype=torch.int8, device=packed.device)
+    with torch.cuda.device(packed.device):
+        _C.call("wanq_unpack_w4", _C.ptr(packed), _C.ptr(out), int(bias), N, K2 * 2, _C.stream())
+    return out
+
+
+def w4a8_of16_nobias_weight_asym_qserve(in_feats, kernel, wscales, ascales, w_szs, a_ssums, out_feats):
+    """Reference signature (ViDiT-Q/kernels/csrc/qgemm/pybind.cpp:12): writes out_feats (fp16 [M, N]).
+    kernel: UNSIGNED 4-bit codes packed two per byte, uint8 [N, K/2] in THIS library's layout (pack_w4(..., bias=0));
+    y = acc * wscales[n] * ascales[m] - w_szs[n] * a_ssums[m]  with w_szs = scale*zero
+    (w4a8_per_channel_gemm_cuda_qserve.cu:580-587)."""
+    codes = unpack_w4(kernel, bias=0)
+    vec = ascales.dtype
+    zp = (-(w_szs.float() / wscales.float())).contiguous()  # asym epilogue: + a_ssum * zp * wscale
+    y = w8a8_linear(in_feats, codes, ascales, wscales.to(vec), None, a_ssums, zp.float(), out_dtype=out_feats.dtype)
+    out_feats.copy_(y)
