@@ -140,7 +140,7 @@ def main():
     from viditq_extension import qgemm
     from wan.configs import SIZE_CONFIGS, WAN_CONFIGS, latent_shape, seq_len_for
     from wan.distributed.parallel import ParallelPlan
-    from wan.utils.fm_solvers import FlowMatchScheduler
+    from wan.utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
 
     cfg = WAN_CONFIGS[args.model]
     # N GPUs = cfg-parallel degree (cond / uncond pass on different GPUs) x Ulysses degree (token sequence sharded)
@@ -154,7 +154,7 @@ def main():
     ctx_c = torch.randn(512, cfg["text_dim"], generator=g, device=dev) * 0.1
     ctx_u = torch.randn(512, cfg["text_dim"], generator=g, device=dev) * 0.1
     total = args.steps + args.warmup
-    sched = FlowMatchScheduler(cfg["num_train_timesteps"], shift=1.0)
+    sched = FlowUniPCMultistepScheduler(cfg["num_train_timesteps"], shift=1.0)  # the reference's default solver
     sched.set_timesteps(max(total, 30), device=dev, shift=5.0)
 
     # ---- the reference's flow on the synthetic model: FP model -> quant_layer_refactor (config) -> calibration pass
@@ -194,16 +194,19 @@ def main():
             cond = model([latent], t, [ctx_c], seq_len, plan.sp)[0]
             uncond = model([latent], t, [ctx_u], seq_len, plan.sp)[0]
         noise = uncond + args.guide * (cond - uncond)
-        return sched.step(noise, latent)
+        return sched.step(noise, sched.timesteps[i], latent)
 
     latent = latent0
     for i in range(args.warmup):
         latent = step(latent, i)
     timer = GemmTimer()
+    atimer = GemmTimer()
+    from wan import ops as wan_ops
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     qgemm.set_timer(timer)
+    wan_ops.set_attention_timer(atimer)
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         latent = step(latent, i)
@@ -212,6 +215,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     qgemm.set_timer(None)
+    wan_ops.set_attention_timer(None)
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -230,10 +234,15 @@ def main():
     }
     if gs:
         ach = gs["ops"] / gs["seconds"]
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_w8a8_kernel (int8 MFMA, all W8A8 linears)", "achieved": ach / 1e12,
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_w8a8_big_kernel / gemm_w8a8_kernel (int8 MFMA, every W8A8 linear)", "achieved": ach / 1e12,
                            "peak": INT8_MFMA_PEAK / 1e12, "unit": "TOP/s", "frac": ach / INT8_MFMA_PEAK, "traffic": None,
                            "launches": gs["launches"], "avg_launch_us": gs["seconds"] / gs["launches"] * 1e6,
                            "gemm_share_of_step": gs["seconds"] / dt}
+    asum = atimer.summary()
+    if asum:  # the FP attention core (not part of the int8 fraction) on its own bf16-MFMA roofline
+        out["attention"] = {"kernel": "attn_fwd_kernel (bf16 MFMA flash attention)", "achieved": asum["ops"] / asum["seconds"] / 1e12,
+                            "peak": 2500.0, "unit": "TFLOP/s", "frac": asum["ops"] / asum["seconds"] / 2.5e15,
+                            "launches": asum["launches"], "share_of_step": asum["seconds"] / dt}
     if rank == 0 and world == 1 and not args.no_quality:
         # deviation of the quantized DiT output from the FP (bf16-autocast) output of the same synthetic model
         t = sched.timesteps[0:1]

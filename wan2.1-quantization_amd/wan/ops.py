@@ -41,6 +41,15 @@ def rope_table(freqs, grid, device):
     return torch.view_as_real(fi).to(torch.float32).contiguous().to(device)
 
 
+_attn_timer = None
+
+
+def set_attention_timer(t):
+    """bench.py hook: a list collecting (start_event, end_event, flops) per attention launch."""
+    global _attn_timer
+    _attn_timer = t
+
+
 def attention(q, k, v, num_heads, k_len=None, out=None):
     """softmax(q k^T / sqrt(d)) v for one sample on the HIP flash-attention kernel (csrc/attention.hip).
     q [Lq, C], k/v [Lk, C] bf16, token-major (row stride may exceed C: column slices of a packed buffer are
@@ -58,8 +67,14 @@ def attention(q, k, v, num_heads, k_len=None, out=None):
     if out is None:
         out = torch.empty(Lq, C, dtype=q.dtype, device=q.device)
     with torch.cuda.device(q.device):
+        if _attn_timer is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         _C.call("wanq_attention_fwd", _C.ptr(q), _C.ptr(k), _C.ptr(v), _C.ptr(out), _C.dt(q), Lq, Lk, num_heads, d,
                 q.stride(0), k.stride(0), v.stride(0), out.stride(0), 1.0 / math.sqrt(d), _C.stream())
+        if _attn_timer is not None:
+            ev1.record()
+            _attn_timer.append((ev0, ev1, 4 * Lq * Lk * d * num_heads))
     return out
 
 

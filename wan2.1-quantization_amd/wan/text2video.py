@@ -16,6 +16,7 @@ import torch
 from .configs import latent_shape, seq_len_for
 from .modules.model import WanModel
 from .utils.fm_solvers import FlowMatchScheduler
+from .utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
 
 logger = logging.getLogger(__name__)
 
@@ -83,7 +84,12 @@ class WanT2V:
 
         if sample_solver not in ("unipc", "dpm++", "euler"):
             raise NotImplementedError(f"Unsupported solver {sample_solver}")
-        sched = FlowMatchScheduler(self.num_train_timesteps, shift=1.0)
+        if sample_solver == "unipc":    # the reference's default (text2video.py:215-222)
+            sched = FlowUniPCMultistepScheduler(self.num_train_timesteps, shift=1.0)
+        elif sample_solver == "euler":  # first-order flow-matching update
+            sched = FlowMatchScheduler(self.num_train_timesteps, shift=1.0)
+        else:
+            raise NotImplementedError("dpm++ is not implemented; use unipc (default) or euler")
         sched.set_timesteps(sampling_steps, device=self.device, shift=shift)
         plan = self.plan
         sp = plan.sp if plan is not None else None
@@ -98,7 +104,7 @@ class WanT2V:
                     cond = self.model([latent], ts, [context], seq_len, **kw)[0]
                     uncond = self.model([latent], ts, [context_null], seq_len, **kw)[0]
                 noise_pred = uncond + guide_scale * (cond - uncond)
-                latent = sched.step(noise_pred, latent)
+                latent = sched.step(noise_pred, t, latent) if sample_solver == "unipc" else sched.step(noise_pred, latent)
                 if step_callback is not None:
                     step_callback(i, latent)
         return latent

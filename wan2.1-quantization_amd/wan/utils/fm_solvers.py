@@ -20,7 +20,7 @@ class FlowMatchScheduler:
         alphas = np.linspace(1, 1 / num_train_timesteps, num_train_timesteps)[::-1].copy()
         sigmas = 1.0 - alphas
         self.sigmas_train = shift * sigmas / (1 + (shift - 1) * sigmas)
-        self.sigma_min, self.sigma_max = float(self.sigmas_train[0]), float(self.sigmas_train[-1])
+        self.sigma_max, self.sigma_min = float(self.sigmas_train[0]), float(self.sigmas_train[-1])  # descending: 0.999 .. 0 (reference :131-132)
         self.timesteps, self.sigmas = None, None
         self._i = 0
 
