@@ -47,6 +47,34 @@ __global__ __launch_bounds__(512, 2) void probe(int* out, long long* cyc, int ni
       FR(wf0, xf0, st, 2) DMA2(2) __builtin_amdgcn_sched_barrier(0); if (MODE == 8) __builtin_amdgcn_s_setprio(1); MM(wf1, xf1) if (MODE == 8) __builtin_amdgcn_s_setprio(0);
       FR(wf1, xf1, st, 3) DMA2(4) __builtin_amdgcn_sched_barrier(0); if (MODE == 8) __builtin_amdgcn_s_setprio(1); MM(wf0, xf0) if (MODE == 8) __builtin_amdgcn_s_setprio(0);
       FR(wf0, xf0, smem + ((it + 1) & 1) * 65536, 0) DMA2(6) __builtin_amdgcn_sched_barrier(0); if (MODE == 8) __builtin_amdgcn_s_setprio(1); MM(wf1, xf1) if (MODE == 8) __builtin_amdgcn_s_setprio(0);
+    } else if (MODE == 9 || MODE == 10) {
+      char* dst = smem + 131072 + wave * 1024;
+#define DMA8() { _Pragma("unroll") for (int q = 0; q < 8; ++q) __builtin_amdgcn_global_load_lds((glb_void*)(gsrc + (((size_t)blockIdx.x * 65536 + (size_t)(it * 8 + q) * 8192) % gspan)), (lds_void*)(dst + (q & 1) * 8192), 16, 0, 0); }
+      const bool early = (MODE == 9) ? (wave < 4) : ((wave & 1) == 0);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if (early) DMA8()
+      FR(wf1, xf1, st, 1) __builtin_amdgcn_sched_barrier(0); MM(wf0, xf0)
+      FR(wf0, xf0, st, 2) __builtin_amdgcn_sched_barrier(0); MM(wf1, xf1)
+      if (!early) DMA8()
+      FR(wf1, xf1, st, 3) __builtin_amdgcn_sched_barrier(0); MM(wf0, xf0)
+      FR(wf0, xf0, smem + ((it + 1) & 1) * 65536, 0) __builtin_amdgcn_sched_barrier(0); MM(wf1, xf1)
+    } else if (MODE == 11 || MODE == 12) {
+      // register-staged: 8 x global_load_dwordx4 issued at the top, written to LDS (ds_write_b128) after the MFMAs;
+      // MODE 12: half by LDS-DMA (4), half register-staged (4)
+      char* dst = smem + 131072 + wave * 1024 + lane * 16;
+      char* dstd = smem + 131072 + wave * 1024;
+      uint4 rg[8];
+      const int nreg = (MODE == 11) ? 8 : 4;
+      _Pragma("unroll") for (int q = 0; q < 8; ++q) {
+        const char* src = gsrc + (((size_t)blockIdx.x * 65536 + (size_t)(it * 8 + q) * 8192) % gspan);
+        if (q < nreg) rg[q] = *(const uint4*)src;
+        else __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dstd + (q & 1) * 8192), 16, 0, 0);
+      }
+      FR(wf1, xf1, st, 1) __builtin_amdgcn_sched_barrier(0); MM(wf0, xf0)
+      FR(wf0, xf0, st, 2) __builtin_amdgcn_sched_barrier(0); MM(wf1, xf1)
+      FR(wf1, xf1, st, 3) __builtin_amdgcn_sched_barrier(0); MM(wf0, xf0)
+      FR(wf0, xf0, smem + ((it + 1) & 1) * 65536, 0) __builtin_amdgcn_sched_barrier(0); MM(wf1, xf1)
+      _Pragma("unroll") for (int q = 0; q < 8; ++q) if (q < nreg) *(uint4*)(dst + (q & 1) * 8192) = rg[q];
     } else if (MODE == 7) {
       if (wave < 4) { char* dst = smem + 131072 + wave * 1024; _Pragma("unroll") for (int q = 0; q < 16; ++q) __builtin_amdgcn_global_load_lds((glb_void*)(gsrc + (((size_t)blockIdx.x * 65536 + (size_t)(it * 16 + q) * 4096) % gspan)), (lds_void*)(dst + (q & 3) * 4096), 16, 0, 0); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
       FR(wf1, xf1, st, 1) __builtin_amdgcn_sched_barrier(0); MM(wf0, xf0)
@@ -86,6 +114,10 @@ int main() {
   RUN(6, 512, "DMA spread 2 per k-step")
   RUN(8, 512, "DMA spread 2 per k-step + setprio(1) on MFMA")
   RUN(7, 512, "DMA by waves 0..3 only (16 each)")
+  RUN(11, 512, "register-staged: 8 global_load_dwordx4 + ds_write_b128")
+  RUN(12, 512, "half LDS-DMA (4) + half register-staged (4)")
+  RUN(9, 512, "DMA: waves 0-3 at k-step 0, waves 4-7 at k-step 2")
+  RUN(10, 512, "DMA: even waves at k-step 0, odd waves at k-step 2")
   RUN(0, 256, "reads(s+1) || mfma(s), 1 wave/SIMD")
   RUN(1, 256, "mfma only, 1 wave/SIMD")
   RUN(2, 256, "reads only, 1 wave/SIMD")

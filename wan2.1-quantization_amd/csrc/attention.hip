@@ -13,11 +13,14 @@
 //   O^T += V^T . P^T   B operand = the S^T accumulator itself, converted to bf16 in place (the accumulator's
 //                      register->key permutation 8(j>>2)+4h+(j&3) is matched by the order in which the A
 //                      operand V^T is gathered with ds_read_b64_tr_b16), so P never touches LDS.
-// K and V tiles are double-buffered in LDS (64 KiB), fetched global->registers one tile ahead and written
-// to LDS in the middle of the iteration (one barrier per tile).  LDS rows are 256 B with the 16-B chunk
-// index XORed by ((row&3)<<2 | (row>>2)&3): conflict-free for the b128 row reads of K, the transposed reads
-// of V and the staging writes.
+// K and V tiles travel global -> LDS by LDS-DMA (global_load_lds_dwordx4) into a ring of three 32-KiB stages, two
+// tiles ahead of the math, published by a counted s_waitcnt vmcnt(4) + one bare s_barrier per tile (DMA = true, the
+// default; +2.8 % over the register-staged two-stage form, DMA = false, kept behind WANQ_ATTN_V1=1).  LDS rows are
+// 256 B with the 16-B chunk index XORed by ((row&3)<<2 | (row>>2)&3): conflict-free for the b128 row reads of K, the
+// transposed reads of V and the staging writes; the DMA writes lane-linearly, so it applies the swizzle on the
+// source side.
 #include "wanq_common.h"
+#include <stdlib.h>
 
 namespace wanq {
 
@@ -43,6 +46,13 @@ __device__ __forceinline__ int at_off(int row, int ch) {
   return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
 }
 
+__device__ __forceinline__ bf16x8 at_join(s16x4 lo, s16x4 hi) {
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, vv);
+}
+
+template <bool DMA>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -88,11 +98,38 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     *reinterpret_cast<uint4*>(sK_ + AT_TILE + st_off1) = rv1;                         \
   } while (0)
 
+  // ---- DMA staging (global_load_lds_dwordx4): instruction i of wave w fills LDS rows 4(2w+i)..+3 of a tile, lane-linear
+  // (16 B per lane), so the chunk swizzle is applied on the SOURCE side: the lane at physical chunk c fetches logical
+  // chunk c ^ swz(row).
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef __attribute__((address_space(1))) const void glb_void;
+  const int d_row0 = 8 * wave + (lane >> 4), d_row1 = d_row0 + 4;
+  const int d_col0 = head * AT_D + (((lane & 15) ^ (((d_row0 & 3) << 2) | ((d_row0 >> 2) & 3))) << 3);
+  const int d_col1 = head * AT_D + (((lane & 15) ^ (((d_row1 & 3) << 2) | ((d_row1 >> 2) & 3))) << 3);
+#define AT_DMA(j, stage)                                                                                        \
+  do {                                                                                                          \
+    int kr0 = (j) * AT_KB + d_row0, kr1 = kr0 + 4;                                                              \
+    kr0 = kr0 < p.Lk ? kr0 : p.Lk - 1;                                                                          \
+    kr1 = kr1 < p.Lk ? kr1 : p.Lk - 1;                                                                          \
+    char* sK_ = smem + (stage) * AT_STAGE + wave * 2048;                                                        \
+    __builtin_amdgcn_global_load_lds((glb_void*)(p.k + (int64_t)kr0 * p.k_stride + d_col0), (lds_void*)(sK_), 16, 0, 0);                  \
+    __builtin_amdgcn_global_load_lds((glb_void*)(p.k + (int64_t)kr1 * p.k_stride + d_col1), (lds_void*)(sK_ + 1024), 16, 0, 0);           \
+    __builtin_amdgcn_global_load_lds((glb_void*)(p.v + (int64_t)kr0 * p.v_stride + d_col0), (lds_void*)(sK_ + AT_TILE), 16, 0, 0);        \
+    __builtin_amdgcn_global_load_lds((glb_void*)(p.v + (int64_t)kr1 * p.v_stride + d_col1), (lds_void*)(sK_ + AT_TILE + 1024), 16, 0, 0); \
+  } while (0)
+
   // ---- transposed-read lane constants for V^T: 16-lane group g, lane 4q+p inside it
   const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
   const int v_row = 4 * (tg >> 1) + tq;                 // + 16 ks (+8 for the second read)
   const int v_ch = 2 * (tg & 1) + (tp >> 1);            // + 4 db
   const int v_half = 8 * (tp & 1);
+
+  // byte addresses (within a stage, before the V-tile / key-slice immediates) of the 8 transposed reads of a key slice
+  const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t va0 = at_off(v_row, 0 + v_ch) + v_half, va1 = at_off(8 + v_row, 0 + v_ch) + v_half;
+  const uint32_t va2 = at_off(v_row, 4 + v_ch) + v_half, va3 = at_off(8 + v_row, 4 + v_ch) + v_half;
+  const uint32_t va4 = at_off(v_row, 8 + v_ch) + v_half, va5 = at_off(8 + v_row, 8 + v_ch) + v_half;
+  const uint32_t va6 = at_off(v_row, 12 + v_ch) + v_half, va7 = at_off(8 + v_row, 12 + v_ch) + v_half;
 
   f32x16 o[4];
 #pragma unroll
@@ -101,26 +138,62 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  AT_GLOAD(0);
-  AT_LSTORE(0);
-  if (nt > 1) AT_GLOAD(1);
-  __syncthreads();
+  if (DMA) {
+    AT_DMA(0, 0);
+    if (nt > 1) {
+      AT_DMA(1, 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+  } else {
+    AT_GLOAD(0);
+    AT_LSTORE(0);
+    if (nt > 1) AT_GLOAD(1);
+    __syncthreads();
+  }
 
+  int st3 = 0;  // DMA: ring of three stages, j % 3
   for (int j = 0; j < nt; ++j) {
-    const int cur = j & 1;
+    const int cur = DMA ? st3 : (j & 1);
     const char* sK = smem + cur * AT_STAGE;
     const char* sV = sK + AT_TILE;
+    // every wave is past the barrier that ended tile j-1, so the stage that held it is free: tile j+2 goes there and has
+    // two tile-times to land
+    const int st_free = st3 == 0 ? 2 : st3 - 1;
+    if (DMA && j + 2 < nt) AT_DMA(j + 2, st_free);
 
     // ---------------- S^T = K . Q^T  (two 32-key blocks)
     f32x16 s0, s1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+    if (DMA) {
+      // K fragments run three d-slices ahead of the MFMAs that consume them
+      bf16x8 kf[8][2];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(sK + at_off(fr, 2 * s + fh));
-      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(sK + at_off(32 + fr, 2 * s + fh));
-      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s], s1, 0, 0, 0);
+      for (int s = 0; s < 3; ++s) {
+        kf[s][0] = *reinterpret_cast<const bf16x8*>(sK + at_off(fr, 2 * s + fh));
+        kf[s][1] = *reinterpret_cast<const bf16x8*>(sK + at_off(32 + fr, 2 * s + fh));
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        if (s + 3 < 8) {
+          kf[s + 3][0] = *reinterpret_cast<const bf16x8*>(sK + at_off(fr, 2 * (s + 3) + fh));
+          kf[s + 3][1] = *reinterpret_cast<const bf16x8*>(sK + at_off(32 + fr, 2 * (s + 3) + fh));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s][0], qf[s], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s][1], qf[s], s1, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(sK + at_off(fr, 2 * s + fh));
+        const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(sK + at_off(32 + fr, 2 * s + fh));
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s], s1, 0, 0, 0);
+      }
     }
     if (j == nt - 1 && (p.Lk & (AT_KB - 1))) {  // ragged last tile: keys >= Lk get -inf
       const int kb = j * AT_KB + 4 * fh;
@@ -172,27 +245,69 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     }
 
     // ---------------- next tile: registers -> other LDS stage, then fetch the tile after it
-    if (j + 1 < nt) {
+    if (!DMA && j + 1 < nt) {
       AT_LSTORE(cur ^ 1);
       if (j + 2 < nt) AT_GLOAD(j + 2);
     }
 
     // ---------------- O^T += V^T . P^T
+    if (DMA) {
+      // The transposed reads go through inline asm here: hipcc puts s_waitcnt vmcnt(0) in front of the builtin form
+      // whenever an LDS-DMA is in flight (it cannot tell the two stages apart), which would serialise the prefetch.
+      // Reads of key slice ks+1 are issued before the MFMAs of slice ks; the counted lgkmcnt wait carries the eight
+      // registers it publishes as operands so that the MFMAs cannot be scheduled above it.
+      const uint32_t vb = lds_base + cur * AT_STAGE;
+      s16x4 ta0, ta1, ta2, ta3, ta4, ta5, ta6, ta7, tb0, tb1, tb2, tb3, tb4, tb5, tb6, tb7;
+#define AT_TR(dst, areg, ks) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(vb + areg), "n"(AT_TILE + 4096 * (ks)))
+#define AT_TR8(P, ks)                                                                                      \
+  AT_TR(P##0, va0, ks); AT_TR(P##1, va1, ks); AT_TR(P##2, va2, ks); AT_TR(P##3, va3, ks);                  \
+  AT_TR(P##4, va4, ks); AT_TR(P##5, va5, ks); AT_TR(P##6, va6, ks); AT_TR(P##7, va7, ks)
+#define AT_WAIT8(P, n)                                                                                     \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(P##0), "+v"(P##1), "+v"(P##2), "+v"(P##3), "+v"(P##4), "+v"(P##5), "+v"(P##6), "+v"(P##7))
+#define AT_PV4(P, ks)                                                                                      \
+  o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_join(P##0, P##1), pf[ks], o[0], 0, 0, 0);              \
+  o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_join(P##2, P##3), pf[ks], o[1], 0, 0, 0);              \
+  o[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_join(P##4, P##5), pf[ks], o[2], 0, 0, 0);              \
+  o[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_join(P##6, P##7), pf[ks], o[3], 0, 0, 0)
+      AT_TR8(ta, 0);
+      AT_TR8(tb, 1);
+      AT_WAIT8(ta, 8);
+      AT_PV4(ta, 0);
+      AT_TR8(ta, 2);
+      AT_WAIT8(tb, 8);
+      AT_PV4(tb, 1);
+      AT_TR8(tb, 3);
+      AT_WAIT8(ta, 8);
+      AT_PV4(ta, 2);
+      AT_WAIT8(tb, 0);
+      AT_PV4(tb, 3);
+#undef AT_TR
+#undef AT_TR8
+#undef AT_WAIT8
+#undef AT_PV4
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-        const char* a0 = sV + at_off(16 * ks + v_row, 4 * db + v_ch) + v_half;
-        const char* a1 = sV + at_off(16 * ks + 8 + v_row, 4 * db + v_ch) + v_half;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a1);
-        typedef short s16x8 __attribute__((ext_vector_type(8)));
-        const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[ks], o[db], 0, 0, 0);
+        for (int db = 0; db < 4; ++db) {
+          typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+          const char* a0 = sV + at_off(16 * ks + v_row, 4 * db + v_ch) + v_half;
+          const char* a1 = sV + at_off(16 * ks + 8 + v_row, 4 * db + v_ch) + v_half;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a1);
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_join(lo, hi), pf[ks], o[db], 0, 0, 0);
+        }
       }
     }
-    __syncthreads();
+    if (DMA) {
+      // tile j+1 must have landed; the four instructions of tile j+2 (if issued) may stay in flight
+      if (j + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      st3 = st3 == 2 ? 0 : st3 + 1;
+      __builtin_amdgcn_s_barrier();  // bare: __syncthreads() would drain vmcnt to 0 and with it the prefetch
+    } else {
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: O[q, d] = O^T[d, q] / l ; lane holds d = 32 db + (r&3) + 8 (r>>2) + 4 fh of query fr
@@ -233,12 +348,17 @@ extern "C" int wanq_attention_fwd(const void* q, const void* k, const void* v, v
   if (Lq == 0) return WANQ_OK;
   AttnParams p{(const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (uint16_t*)o, q_stride, k_stride, v_stride, o_stride,
                (int)Lq, (int)Lk, heads, scale * 1.4426950408889634f};
+  // Default: LDS-DMA staging into a three-stage ring (96 KiB).  WANQ_ATTN_V1=1 selects the register-staged two-stage form
+  // (64 KiB) kept for A/B timing.
+  static const bool v1 = [] { const char* e = getenv("WANQ_ATTN_V1"); return e && e[0] == '1'; }();
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_STAGE);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_STAGE);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * AT_STAGE);
     attr_set = true;
   }
   dim3 grid((unsigned)((Lq + AT_QB - 1) / AT_QB), (unsigned)heads);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(512), 2 * AT_STAGE, (hipStream_t)stream, p);
+  if (v1) hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(512), 2 * AT_STAGE, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(512), 3 * AT_STAGE, (hipStream_t)stream, p);
   return check_launch("wanq_attention_fwd");
 }
