@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void gemm_w8a8_kernel(const GemmParams p) {
           }
           if (p.epi & WANQ_EPI_GELU) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_f32(y[e]);
+            for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_fast_f32(y[e]);
           }
           if (p.epi & WANQ_EPI_GATE_RES) {
             float g4[4], r4[4];
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
               y[e] = fmaf((float)acc[i][j][4 * g + e] * sa_m[j], swa[e], fmaf(asum_m[j], zsa[e], ba[e]));
             if (p.epi & WANQ_EPI_GELU) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_f32(y[e]);
+              for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_fast_f32(y[e]);
             }
             if (has_res) {
 #pragma unroll
