@@ -37,6 +37,25 @@ struct GemmParams {
   int mt, nt;
 };
 
+template <int OUT>
+__device__ __forceinline__ uint2 pack16x4(const float (&y)[4]) {
+  uint2 v;
+  if (OUT == WANQ_F16) {
+    __half2* h = reinterpret_cast<__half2*>(&v);
+    h[0] = __floats2half2_rn(y[0], y[1]);
+    h[1] = __floats2half2_rn(y[2], y[3]);
+  } else {
+    uint16_t b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const __hip_bfloat16 t = __float2bfloat16(y[j]);
+      b[j] = *reinterpret_cast<const uint16_t*>(&t);
+    }
+    v = make_uint2((uint32_t)b[0] | ((uint32_t)b[1] << 16), (uint32_t)b[2] | ((uint32_t)b[3] << 16));
+  }
+  return v;
+}
+
 constexpr int BM = 128, BN = 128, BK = 128;
 constexpr int STAGE_BYTES = (BM + BN) * BK;  // 32 KiB
 constexpr int GROUP_M = 8;
@@ -355,6 +374,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
       // vector-memory ops), then the barrier makes that true for every wave and also says every wave has
       // finished reading the other stage.
       if (pending_stores == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (pending_stores == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
       pending_stores = 0;
       __builtin_amdgcn_s_barrier();
@@ -440,37 +460,29 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
       if (!has_res) B2_ISSUE(0, 0);
     }
     const bool full_tile = (cur_m0 + B2M <= p.M) && (cur_n0 + B2N <= p.N);
+    // ---- store loop.  An accumulator has one token per lane and 4 channels per register quad, so storing it directly
+    // writes 8-16 B per lane at a row stride: 32 partial lines per instruction (PMC: WRITE_SIZE 2.6-2.7x the output
+    // bytes).  Each wave therefore turns its results through a private 4-KiB LDS buffer (32 tokens x 128 B, 16-B chunks
+    // XORed with row&7; stage 1 is free until the next tile's second K-tile) and stores -- and reads the residual --
+    // as whole 128-B lines, 8 lanes per line.  Same-wave LDS traffic only: no barrier.
+    char* tb = smem + B2_STAGE + 4096 + wave * 4096;
+    const int rd_row = lane >> 3, rd_c = lane & 7;  // read-back: row rd_row + 8*pass, 16-B chunk rd_c
+    const int tok_base = cur_m0 + wm * 128;
+    constexpr bool OUT16 = (OUT == WANQ_F16 || OUT == WANQ_BF16);
+    if (OUT16 && !has_res) {
+      // chunk = 32 tokens x 64 channels in the output type
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+      for (int j = 0; j < 4; ++j) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int nl = wn * 64 + i * 32 + 8 * g + 4 * fh;  // channel inside the tile
-        const int n = cur_n0 + nl;
-        const bool n_ok = n < p.N;
-        float4 sw4 = make_float4(1.f, 1.f, 1.f, 1.f), zs4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = zs4, g4 = zs4;
-        if (OUT != WANQ_I32) {
-          sw4 = *reinterpret_cast<const float4*>(chan + nl);
-          zs4 = *reinterpret_cast<const float4*>(chan + 256 + nl);
-          b4 = *reinterpret_cast<const float4*>(chan + 512 + nl);
-          if (has_res) g4 = *reinterpret_cast<const float4*>(chan + 768 + nl);
-        }
-        const float swa[4] = {sw4.x, sw4.y, sw4.z, sw4.w}, zsa[4] = {zs4.x, zs4.y, zs4.z, zs4.w};
-        const float ba[4] = {b4.x, b4.y, b4.z, b4.w}, ga[4] = {g4.x, g4.y, g4.z, g4.w};
-        float r4[4][4];
-        if (OUT != WANQ_I32 && has_res) {
+        for (int i = 0; i < 2; ++i) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            OutIo<OUT == WANQ_I32 ? WANQ_F32 : OUT>::load4(p.residual, (int64_t)mcl[j] * p.N + (n_ok ? n : 0), r4[j]);
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (!full_tile && (mrow[j] >= p.M || !n_ok)) continue;
-          const int64_t o = (int64_t)mrow[j] * p.N + n;
-          if (OUT == WANQ_I32) {
-            *reinterpret_cast<int4*>(static_cast<int*>(p.out) + o) =
-                make_int4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-          } else {
+          for (int g = 0; g < 4; ++g) {
+            const int nl = wn * 64 + i * 32 + 8 * g + 4 * fh;
+            const float4 sw4 = *reinterpret_cast<const float4*>(chan + nl);
+            const float4 zs4 = *reinterpret_cast<const float4*>(chan + 256 + nl);
+            const float4 b4 = *reinterpret_cast<const float4*>(chan + 512 + nl);
+            const float swa[4] = {sw4.x, sw4.y, sw4.z, sw4.w}, zsa[4] = {zs4.x, zs4.y, zs4.z, zs4.w};
+            const float ba[4] = {b4.x, b4.y, b4.z, b4.w};
             float y[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e)  // acc*sA*sW + (sumA*(zp*sW) + bias)
@@ -479,23 +491,88 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
 #pragma unroll
               for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_fast_f32(y[e]);
             }
-            if (has_res) {
+            const int cb = (i * 32 + 8 * g + 4 * fh) * 2;  // byte column inside the 128-B row
+            *reinterpret_cast<uint2*>(tb + fr * 128 + ((((cb >> 4) ^ (fr & 7)) << 4) | (cb & 15))) = pack16x4<OUT>(y);
+          }
+        }
 #pragma unroll
-              for (int e = 0; e < 4; ++e) y[e] = fmaf(y[e], ga[e], r4[j][e]);
+        for (int ps = 0; ps < 4; ++ps) {
+          const int row = rd_row + 8 * ps;
+          const uint4 v = *reinterpret_cast<const uint4*>(tb + row * 128 + ((rd_c ^ (row & 7)) << 4));
+          const int tok = tok_base + j * 32 + row;
+          const int n = cur_n0 + wn * 64 + rd_c * 8;
+          if (full_tile || (tok < p.M && n < p.N))
+            *reinterpret_cast<uint4*>(static_cast<uint16_t*>(p.out) + (int64_t)tok * p.N + n) = v;
+        }
+      }
+    } else {
+      // chunk = 32 tokens x 32 channels of fp32 / int32; gate*y + residual is applied after the turn, on whole lines
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int cb = (8 * g + 4 * fh) * 4;
+            char* dst = tb + fr * 128 + ((((cb >> 4) ^ (fr & 7)) << 4));
+            if (OUT == WANQ_I32) {
+              *reinterpret_cast<int4*>(dst) =
+                  make_int4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+            } else {
+              const int nl = wn * 64 + i * 32 + 8 * g + 4 * fh;
+              const float4 sw4 = *reinterpret_cast<const float4*>(chan + nl);
+              const float4 zs4 = *reinterpret_cast<const float4*>(chan + 256 + nl);
+              const float4 b4 = *reinterpret_cast<const float4*>(chan + 512 + nl);
+              const float swa[4] = {sw4.x, sw4.y, sw4.z, sw4.w}, zsa[4] = {zs4.x, zs4.y, zs4.z, zs4.w};
+              const float ba[4] = {b4.x, b4.y, b4.z, b4.w};
+              float y[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                y[e] = fmaf((float)acc[i][j][4 * g + e] * sa_m[j], swa[e], fmaf(asum_m[j], zsa[e], ba[e]));
+              if (p.epi & WANQ_EPI_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_fast_f32(y[e]);
+              }
+              *reinterpret_cast<float4*>(dst) = make_float4(y[0], y[1], y[2], y[3]);
             }
-            OutIo<OUT == WANQ_I32 ? WANQ_F32 : OUT>::store4(p.out, o, y);
+          }
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps) {
+            const int row = rd_row + 8 * ps;
+            const char* src = tb + row * 128 + ((rd_c ^ (row & 7)) << 4);
+            const int tok = tok_base + j * 32 + row;
+            const int nl = wn * 64 + i * 32 + rd_c * 4;
+            const int n = cur_n0 + nl;
+            if (!(full_tile || (tok < p.M && n < p.N))) continue;
+            const int64_t o = (int64_t)tok * p.N + n;
+            if (OUT == WANQ_I32) {
+              *reinterpret_cast<int4*>(static_cast<int*>(p.out) + o) = *reinterpret_cast<const int4*>(src);
+            } else {
+              const float4 v = *reinterpret_cast<const float4*>(src);
+              float y[4] = {v.x, v.y, v.z, v.w};
+              if (has_res) {
+                float r4[4];
+                OutIo<OUT == WANQ_I32 ? WANQ_F32 : OUT>::load4(p.residual, o, r4);
+                const float4 g4 = *reinterpret_cast<const float4*>(chan + 768 + nl);
+                y[0] = fmaf(y[0], g4.x, r4[0]);
+                y[1] = fmaf(y[1], g4.y, r4[1]);
+                y[2] = fmaf(y[2], g4.z, r4[2]);
+                y[3] = fmaf(y[3], g4.w, r4[3]);
+              }
+              OutIo<OUT == WANQ_I32 ? WANQ_F32 : OUT>::store4(p.out, o, y);
+            }
           }
         }
       }
     }
     if (next >= ntiles) break;
-    // A full tile issues exactly 32 store instructions per wave after the LDS-DMA above; a ragged tile may
-    // issue fewer (whole-wave skips), so it falls back to a full drain.
+    // A full tile issues exactly 16 (16-bit output) or 32 store instructions per wave after the LDS-DMA above; a ragged
+    // tile may issue fewer (whole-wave skips), so it falls back to a full drain.
     if (has_res) {
       B2_ISSUE(0, 0);  // behind the stores: the first barrier of the next tile drains them (vmcnt(0))
       pending_stores = 0;
     } else {
-      pending_stores = full_tile ? 32 : 0;
+      pending_stores = full_tile ? (OUT16 ? 16 : 32) : 0;
     }
     tile = next;
   }
