@@ -35,6 +35,7 @@ struct GemmParams {
   int tok_dtype, ch_dtype, zp_dtype, epi;
   int M, N, K;
   int mt, nt;
+  int group_m;  // v2: m-tiles per L2 panel
 };
 
 template <int OUT>
@@ -58,7 +59,7 @@ __device__ __forceinline__ uint2 pack16x4(const float (&y)[4]) {
 
 constexpr int BM = 128, BN = 128, BK = 128;
 constexpr int STAGE_BYTES = (BM + BN) * BK;  // 32 KiB
-constexpr int GROUP_M = 8;
+constexpr int GROUP_M = 4;  // m-tiles per L2 panel (sweep 2..32 on cfg-B: 4 best, 8 within 1-3 %; WANQ_GEMM_GROUP_M overrides)
 static bool g_force_v1 = false;  // test hook: WANQ_GEMM_V1=1 in the environment
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -310,10 +311,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
   auto tile_origin = [&](int t, int& m0, int& n0) {
     const int xq = ntiles >> 3, xr = ntiles & 7, xcd = t & 7;
     const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (t >> 3);
-    const int per_group = GROUP_M * p.nt;
+    const int per_group = p.group_m * p.nt;
     const int group = wg / per_group;
-    const int first_m = group * GROUP_M;
-    const int gsz = (p.mt - first_m < GROUP_M) ? (p.mt - first_m) : GROUP_M;
+    const int first_m = group * p.group_m;
+    const int gsz = (p.mt - first_m < p.group_m) ? (p.mt - first_m) : p.group_m;
     const int in_g = wg - group * per_group;
     m0 = (first_m + in_g % gsz) * B2M;
     n0 = (in_g / gsz) * B2N;
@@ -631,10 +632,11 @@ extern "C" int wanq_gemm_w8a8(const int8_t* a, const int8_t* w, void* out, int o
     static const bool v1 = [] { const char* e = getenv("WANQ_GEMM_V1"); return e && e[0] == '1'; }();
     g_force_v1 = v1;
   }
+  static const int group_m = [] { const char* e = getenv("WANQ_GEMM_GROUP_M"); const int v = e ? atoi(e) : 0; return v > 0 ? v : GROUP_M; }();
   GemmParams p{};
   p.a = a; p.w = w; p.out = out; p.sa = sa; p.asum = asum; p.sw = sw; p.bias = bias; p.zp = zp; p.gate = gate;
   p.residual = residual; p.tok_dtype = tok_dtype; p.ch_dtype = ch_dtype; p.zp_dtype = zp_dtype; p.epi = epi_flags;
-  p.M = (int)M; p.N = N; p.K = K;
+  p.M = (int)M; p.N = N; p.K = K; p.group_m = group_m;
   p.mt = (int)((M + BM - 1) / BM);
   p.nt = (N + BN - 1) / BN;
   WANQ_REQUIRE((int64_t)p.mt * p.nt < (1ll << 31), WANQ_E_SHAPE, "wanq_gemm_w8a8: too many tiles");
