@@ -16,7 +16,8 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void peak_kernel(const float* in, float* out, int iters) {
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void peak_kernel(const float* in, float* out, int iters, unsigned long long* clk) {
+  const unsigned long long c0 = clock64(), w0 = wall_clock64();
   const int lane = threadIdx.x & 63;
   bf16x8 a[8], b[4];
   for (int i = 0; i < 8; ++i)
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void peak_kernel(const float
   for (int i = 0; i < 4; ++i)
     for (int r = 0; r < 16; ++r) acc += o[i][r];
   out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
 }
 
 int main() {
@@ -65,6 +67,8 @@ int main() {
   float *in, *out;
   hipMalloc(&in, 256 * 4);
   hipMalloc(&out, blocks * WAVES * 64 * 4);
+  unsigned long long* clk;
+  hipMalloc(&clk, 16);
   float h[256];
   for (int i = 0; i < 256; ++i) h[i] = (float)((i * 37) % 17 - 8) * 0.01f;
   hipMemcpy(in, h, sizeof(h), hipMemcpyHostToDevice);
@@ -73,13 +77,18 @@ int main() {
   hipEventCreate(&e1);
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL(peak_kernel, dim3(blocks), dim3(WAVES * 64), 0, 0, in, out, iters);
+    hipLaunchKernelGGL(peak_kernel, dim3(blocks), dim3(WAVES * 64), 0, 0, in, out, iters, clk);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     const double flops = 2.0 * 32 * 32 * 16 * 32.0 * iters * (double)blocks * WAVES;
-    printf("MODE %d WAVES %d: %.3f ms  %.1f TFLOP/s (%.1f %% of 2.5 PF)\n", MODE, WAVES, ms, flops / ms * 1e-9, flops / ms * 1e-9 / 2500 * 100);
+    unsigned long long hc[2];
+    hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost);
+    // workgroup 0: MFMA issue cycles it should have taken at 32 cycles per MFMA per SIMD vs its wall time (100 MHz counter)
+    const double wg_us = hc[1] / 100.0, mfma_cycles = 32.0 * 32 * iters * (WAVES / 4);
+    printf("MODE %d WAVES %d: %.3f ms  %.1f TFLOP/s (%.1f %% of 2.5 PF) | wg0: clock64 %llu, wall %.1f us -> >= %.0f MHz if the matrix pipe never idled\n",
+           MODE, WAVES, ms, flops / ms * 1e-9, flops / ms * 1e-9 / 2500 * 100, hc[0], wg_us, mfma_cycles / wg_us);
   }
   return 0;
 }

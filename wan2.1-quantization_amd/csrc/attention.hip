@@ -106,16 +106,31 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
   const int d_row0 = 8 * wave + (lane >> 4), d_row1 = d_row0 + 4;
   const int d_col0 = head * AT_D + (((lane & 15) ^ (((d_row0 & 3) << 2) | ((d_row0 >> 2) & 3))) << 3);
   const int d_col1 = head * AT_D + (((lane & 15) ^ (((d_row1 & 3) << 2) | ((d_row1 >> 2) & 3))) << 3);
+  // Per-lane byte offsets inside a tile are constants; a tile's base address is wave-uniform (scalar ALU), so a DMA costs no
+  // vector arithmetic: `base + zero-extended 32-bit lane offset` is the instruction's own sgpr + vgpr addressing.  (The
+  // 64-bit `row * stride` per lane and instruction it replaces cost ~20 quarter-rate integer multiplies per tile and
+  // wave -- 0.45-0.8 ms of a 6-ms kernel.)  Only a ragged last tile clamps rows, on the slow path.
+  const uint32_t d_kb0 = (uint32_t)(d_row0 * (int)p.k_stride + d_col0) * 2u, d_kb1 = (uint32_t)(d_row1 * (int)p.k_stride + d_col1) * 2u;
+  const uint32_t d_vb0 = (uint32_t)(d_row0 * (int)p.v_stride + d_col0) * 2u, d_vb1 = (uint32_t)(d_row1 * (int)p.v_stride + d_col1) * 2u;
 #define AT_DMA(j, stage)                                                                                        \
   do {                                                                                                          \
-    int kr0 = (j) * AT_KB + d_row0, kr1 = kr0 + 4;                                                              \
-    kr0 = kr0 < p.Lk ? kr0 : p.Lk - 1;                                                                          \
-    kr1 = kr1 < p.Lk ? kr1 : p.Lk - 1;                                                                          \
     char* sK_ = smem + (stage) * AT_STAGE + wave * 2048;                                                        \
-    __builtin_amdgcn_global_load_lds((glb_void*)(p.k + (int64_t)kr0 * p.k_stride + d_col0), (lds_void*)(sK_), 16, 0, 0);                  \
-    __builtin_amdgcn_global_load_lds((glb_void*)(p.k + (int64_t)kr1 * p.k_stride + d_col1), (lds_void*)(sK_ + 1024), 16, 0, 0);           \
-    __builtin_amdgcn_global_load_lds((glb_void*)(p.v + (int64_t)kr0 * p.v_stride + d_col0), (lds_void*)(sK_ + AT_TILE), 16, 0, 0);        \
-    __builtin_amdgcn_global_load_lds((glb_void*)(p.v + (int64_t)kr1 * p.v_stride + d_col1), (lds_void*)(sK_ + AT_TILE + 1024), 16, 0, 0); \
+    if (((j) + 1) * AT_KB <= p.Lk) {                                                                            \
+      const char* kt_ = reinterpret_cast<const char*>(p.k) + (int64_t)(j) * (AT_KB * 2) * p.k_stride;           \
+      const char* vt_ = reinterpret_cast<const char*>(p.v) + (int64_t)(j) * (AT_KB * 2) * p.v_stride;           \
+      __builtin_amdgcn_global_load_lds((glb_void*)(kt_ + d_kb0), (lds_void*)(sK_), 16, 0, 0);                   \
+      __builtin_amdgcn_global_load_lds((glb_void*)(kt_ + d_kb1), (lds_void*)(sK_ + 1024), 16, 0, 0);            \
+      __builtin_amdgcn_global_load_lds((glb_void*)(vt_ + d_vb0), (lds_void*)(sK_ + AT_TILE), 16, 0, 0);         \
+      __builtin_amdgcn_global_load_lds((glb_void*)(vt_ + d_vb1), (lds_void*)(sK_ + AT_TILE + 1024), 16, 0, 0);  \
+    } else {                                                                                                    \
+      int kr0 = (j) * AT_KB + d_row0, kr1 = kr0 + 4;                                                            \
+      kr0 = kr0 < p.Lk ? kr0 : p.Lk - 1;                                                                        \
+      kr1 = kr1 < p.Lk ? kr1 : p.Lk - 1;                                                                        \
+      __builtin_amdgcn_global_load_lds((glb_void*)(p.k + (int64_t)kr0 * p.k_stride + d_col0), (lds_void*)(sK_), 16, 0, 0);                  \
+      __builtin_amdgcn_global_load_lds((glb_void*)(p.k + (int64_t)kr1 * p.k_stride + d_col1), (lds_void*)(sK_ + 1024), 16, 0, 0);           \
+      __builtin_amdgcn_global_load_lds((glb_void*)(p.v + (int64_t)kr0 * p.v_stride + d_col0), (lds_void*)(sK_ + AT_TILE), 16, 0, 0);        \
+      __builtin_amdgcn_global_load_lds((glb_void*)(p.v + (int64_t)kr1 * p.v_stride + d_col1), (lds_void*)(sK_ + AT_TILE + 1024), 16, 0, 0); \
+    }                                                                                                           \
   } while (0)
 
   // ---- transposed-read lane constants for V^T: 16-lane group g, lane 4q+p inside it
