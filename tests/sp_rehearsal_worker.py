@@ -1,0 +1,117 @@
+"""Worker for tests/test_gpu_sp_rehearsal.py: two ranks on ONE GPU rehearse the multi-GPU path of the kernel-mode model.
+
+RCCL refuses two ranks on the same device, so the process group is gloo and the three collectives the parallel module uses
+are staged through host memory here (test scaffolding only; the product path calls torch.distributed directly with
+backend "nccl").  Everything else -- sequence sharding, per-rank RoPE slice, head scatter / gather around the HIP attention
+kernel on H/P heads, the final row all-gather, the cfg-parallel all-gather -- is the product code, on the HIP kernels."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "wan2.1-quantization_amd"))
+
+
+class _Work:
+    def wait(self):
+        return True
+
+
+def _stage_collectives():
+    a2a, agt, ag = dist.all_to_all_single, dist.all_gather_into_tensor, dist.all_gather
+
+    def all_to_all_single(output, input, group=None, async_op=False, **kw):
+        o = torch.empty(output.shape, dtype=output.dtype)
+        a2a(o, input.cpu(), group=group)
+        output.copy_(o)
+        return _Work() if async_op else None
+
+    def all_gather_into_tensor(output, input, group=None, async_op=False):
+        o = torch.empty(output.shape, dtype=output.dtype)
+        agt(o, input.cpu(), group=group)
+        output.copy_(o)
+        return _Work() if async_op else None
+
+    def all_gather(tensor_list, tensor, group=None, async_op=False):
+        tmp = [torch.empty(t.shape, dtype=t.dtype) for t in tensor_list]
+        ag(tmp, tensor.cpu(), group=group)
+        for d, s in zip(tensor_list, tmp):
+            d.copy_(s)
+        return _Work() if async_op else None
+
+    dist.all_to_all_single, dist.all_gather_into_tensor, dist.all_gather = all_to_all_single, all_gather_into_tensor, all_gather
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", init_method="env://")
+    _stage_collectives()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+
+    from qdiff import config as qcfg
+    from qdiff.base.quant_layer import QuantizedLinear
+    from wan import calib
+    from wan.configs import seq_len_for
+    from wan.distributed.parallel import ParallelPlan
+    from wan.modules.model import WanModel
+    from wan.quant_wanx import QuantWanModel
+
+    torch.manual_seed(0)
+    with torch.device(dev):
+        fp = WanModel(dim=512, ffn_dim=1024, num_heads=4, num_layers=2, text_dim=64, freq_dim=64).eval()
+    g = torch.Generator(device=dev).manual_seed(1)
+    for m in fp.modules():
+        if isinstance(m, torch.nn.Linear) and m.bias is not None:
+            m.bias.data.normal_(std=0.02, generator=g)
+    torch.nn.init.xavier_uniform_(fp.head.head.weight, generator=g)
+    shape = (16, 3, 20, 18)  # 3 * 10 * 9 = 270 tokens: odd per-rank counts are covered by the padded sequence length
+    latent = torch.randn(shape, generator=g, device=dev)
+    ctx_c = torch.randn(24, 64, generator=g, device=dev) * 0.1
+    ctx_u = torch.randn(24, 64, generator=g, device=dev) * 0.1
+    t = torch.tensor([500], device=dev)
+
+    quant_config = qcfg.load(os.path.join(ROOT, "wan2.1-quantization_amd", "quant_configs", "w8a8_all_linears.yaml"))
+    model = QuantWanModel.from_float(fp, quant_config)
+    model.quant_layer_refactor()
+    hooks = calib.add_hooks(fp)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        fp([latent], t, [ctx_c], seq_len_for(shape))
+    calib_data = calib.gather_and_save_activation(hooks)
+    gen = torch.Generator().manual_seed(0)
+    for name, mod in model.named_modules():
+        if isinstance(mod, QuantizedLinear) and (mod.uses_mask or mod.uses_rotation):
+            calib.init_rotation_and_channel_mask_(mod, name, calib_data, gen)
+    model.set_init_done()
+    model.hardware_forward_refactor()
+
+    ref_c = model([latent], t, [ctx_c], seq_len_for(shape))[0]
+    ref_u = model([latent], t, [ctx_u], seq_len_for(shape))[0]
+
+    def rel(a, b):
+        return ((a - b).norm() / b.norm()).item()
+
+    # ---- Ulysses over both ranks (cfg 1 x sp 2)
+    plan = ParallelPlan(world, rank, 1, world)
+    assert plan.sp.size == world
+    sl = seq_len_for(shape, sp_size=world)
+    out = model([latent], t, [ctx_c], sl, plan.sp)[0]
+    e_sp = rel(out, ref_c)
+    # ---- CFG parallel (cfg 2 x sp 1): each rank runs one of the two passes
+    plan2 = ParallelPlan(world, rank, 2, 1)
+    mine = model([latent], t, [ctx_c if plan2.cfg_index == 0 else ctx_u], seq_len_for(shape), plan2.sp)[0]
+    cond, uncond = plan2.gather_cfg(mine)
+    e_cfg = max(rel(cond, ref_c), rel(uncond, ref_u))
+    torch.cuda.synchronize()
+    print(f"RANK {rank} sp_rel={e_sp:.3e} cfg_rel={e_cfg:.3e} finite={bool(torch.isfinite(out).all())}", flush=True)
+    # sharding changes no arithmetic: per-token quantisation, per-head attention and row-parallel GEMMs are shard-local
+    assert e_sp < 1e-5, e_sp
+    assert e_cfg < 1e-6, e_cfg
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

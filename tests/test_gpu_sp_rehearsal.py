@@ -1,0 +1,26 @@
+"""Multi-rank rehearsal on ONE GPU (2 processes, gloo rendezvous on 127.0.0.1): the kernel-mode model under Ulysses
+sequence parallelism and under CFG parallelism must reproduce the single-rank output.  See sp_rehearsal_worker.py."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_ranks_on_one_gpu_match_single_rank():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(HERE, "sp_rehearsal_worker.py")]
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, f"rehearsal failed:\n{r.stdout[-4000:]}\n{r.stderr[-4000:]}"
+    assert r.stdout.count("sp_rel=") == 2, r.stdout[-2000:]
