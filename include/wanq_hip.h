@@ -158,6 +158,17 @@ int wanq_layernorm_rotate_quant_rows(const void* x, int x_dtype, const void* gam
                                      float eps, const float* premul, const float* hadk, int had_k, int8_t* q,
                                      void* scale, void* sum, int vec_dtype, int64_t rows, int cols, void* stream);
 
+/* The same, for up to three consumers of ONE normalised row: self-attention q / k / v share norm1 and the modulation
+ * (ViDiT-Q/examples/Wan2.1/wan/modules/model.py:327-331) but each ViDiTQuantizedLinear has its own channel mask and
+ * rotation signs (viditq_quant_layer.py:30-38), so the reference normalises, scales, rotates (fp64 GEMM) and quantises
+ * three times.  Here x is read and normalised once; set t gets hadU(LN(x) * premul[t]) quantised into q[t] / scale[t] /
+ * sum[t].  premul / q / scale / sum are host arrays of nsets (1..3) device pointers; hadk / had_k are shared. */
+int wanq_layernorm_rotate_quant_rows_multi(const void* x, int x_dtype, const void* gamma, const void* mshift,
+                                           const void* mscale, int mod_dtype, int64_t mod_stride, int64_t rows_per_batch,
+                                           float eps, int nsets, const float* const* premul, const float* hadk, int had_k,
+                                           int8_t* const* q, void* const* scale, void* const* sum, int vec_dtype,
+                                           int64_t rows, int cols, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * 4-bit weight storage.  packed[r, j] = (q[r,2j] + bias) | (q[r,2j+1] + bias) << 4, bias 8 for signed codes in
  * [-8,7] (qdiff 4-bit asym, base_quantizer.py:32,89-90), bias 0 for unsigned codes 0..15 (QServe convention,

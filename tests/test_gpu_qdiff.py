@@ -81,6 +81,34 @@ def test_layernorm_rotate_quant_vs_oracle():
     assert d.max() <= 1 and (d != 0).mean() < 3e-3
 
 
+@pytest.mark.parametrize("n,rows", [(1536, 70), (5120, 9), (256, 5)])
+def test_layernorm_rotate_quant_multi_equals_three_single_calls(n, rows):
+    """One pass over x for the q / k / v consumers of a block == three independent passes, bit for bit (codes, scales,
+    sums), including ragged row counts (surplus waves of the last workgroup) and the 4-waves-per-row variant (5120)."""
+    import viditq_extension.fused as fused
+    from qdiff.quarot import quarot_utils as qu
+
+    g = torch.Generator().manual_seed(n + rows)
+    x = (torch.randn(rows, n, generator=g) * 2 + 0.1).to(DEV)
+    sh, sc = (torch.randn(1, n, generator=g) * 0.2).to(DEV), (torch.randn(1, n, generator=g) * 0.2).to(DEV)
+    pms = [((torch.rand(n, generator=g) + 0.5) * (torch.randint(0, 2, (n,), generator=g) * 2 - 1)).to(DEV) for _ in range(3)]
+    rot = qu.kernel_rotation_params(n, DEV)
+    single = []
+    for pm in pms:
+        q = torch.empty(rows, n, dtype=torch.int8, device=DEV)
+        scale, ssum = torch.zeros(rows, device=DEV), torch.zeros(rows, device=DEV)
+        fused.layernorm_rotate_quant(q, x, None, sh, sc, pm, rot, ssum, scale, 1e-6)
+        single.append((q, scale, ssum))
+    for k in (2, 3):
+        qs = [torch.empty(rows, n, dtype=torch.int8, device=DEV) for _ in range(k)]
+        scales, sums = [torch.zeros(rows, device=DEV) for _ in range(k)], [torch.zeros(rows, device=DEV) for _ in range(k)]
+        fused.layernorm_rotate_quant_multi(qs, x, None, sh, sc, pms[:k], rot, sums, scales, 1e-6)
+        for i in range(k):
+            assert torch.equal(qs[i], single[i][0]) and torch.equal(scales[i], single[i][1]) and torch.equal(sums[i], single[i][2])
+    with pytest.raises(RuntimeError):
+        fused.layernorm_rotate_quant_multi([single[0][0]] * 4, x, None, sh, sc, pms + pms[:1], rot, [single[0][2]] * 4, [single[0][1]] * 4, 1e-6)
+
+
 def test_quantized_linear_vs_reference_golden(golden):
     """qdiff.QuantizedLinear (int8 GEMM inside) == the reference's QuantizedLinear.forward output (golden a3)."""
     from qdiff.base.quant_layer import QuantizedLinear

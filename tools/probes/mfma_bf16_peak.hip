@@ -2,6 +2,7 @@
 //   MODE 0: 4 independent accumulators, operands in registers, no other work
 //   MODE 1: the attention dependency shape per "tile": 16 MFMAs on 2 accumulators (S), accumulators -> bf16 (cvt),
 //           16 MFMAs on 4 accumulators with the converted values as B operand (PV)
+//   MODE 2: v_mfma_f32_16x16x32_bf16, 16 independent accumulators, same FLOPs per iteration as MODE 0
 // WAVES = waves per workgroup (4 = one per SIMD, 8 = two per SIMD); one workgroup per CU x 256 CUs x REPS rounds.
 // Build: hipcc -O3 --offload-arch=gfx950 -DMODE=0 -DWAVES=8 mfma_bf16_peak.hip -o mfma_bf16_peak
 #include <hip/hip_runtime.h>
@@ -28,7 +29,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void peak_kernel(const float
   for (int i = 0; i < 4; ++i)
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   for (int it = 0; it < iters; ++it) {
-#if MODE == 0
+#if MODE == 2
+    // same FLOPs per iteration with v_mfma_f32_16x16x32_bf16: 64 MFMAs on 16 accumulators of 4 registers
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4* o4 = reinterpret_cast<f32x4*>(o);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o4[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(s + i) & 7], b[i & 3], o4[i], 0, 0, 0);
+#elif MODE == 0
 #pragma unroll
     for (int s = 0; s < 8; ++s)
 #pragma unroll

@@ -39,6 +39,13 @@ struct RowParams {
   const float* hadk;    // [K, K] +-1 matrix (row-major) or NULL when K == 1
   int had_k;            // 0 = no rotation; else cols == had_k * 128
   float had_div;        // fp32 sqrt(cols): the reference divides by torch.tensor(n).sqrt()
+  // further (premul, q, scale, sum) sets computed from the SAME normalised row (q / k / v of one block share LayerNorm and
+  // modulation but have their own channel mask and rotation signs): nsets in 1..3, set 0 = the fields above
+  int nsets;
+  const float* premul_n[2];
+  int8_t* q_n[2];
+  void* scale_n[2];
+  void* sum_n[2];
 };
 
 __device__ __forceinline__ void load8_rt(const void* base, int dt, int64_t elem, float (&v)[8]) {
@@ -92,8 +99,38 @@ struct RowReduce {
 
 // Hadamard rotation (H_K (x) H_128) / sqrt(n) of a row held in registers.  With 8-element chunks, element e =
 // 8*chunk + j has block index k = chunk >> 4 and in-block index r = 8*(chunk & 15) + j, and chunk & 15 == lane & 15:
-// the 128-point Walsh-Hadamard transform is 3 in-register stages (bits of j) + 4 cross-lane stages (lane bits
-// 0..3, inside a DPP row); the K x K mixing goes through LDS ([k][128] fp32, conflict-free b128 reads).
+// the 128-point Walsh-Hadamard transform is 3 in-register stages (bits of j) + 4 cross-lane stages (lane bits 0..3, inside
+// a DPP row of 16 lanes); the K x K mixing goes through LDS ([k][128] fp32, conflict-free b128 reads).
+// Both halves are arranged to stay off the LDS pipe, which four SIMDs share (the first version spent 200 LDS
+// instructions per wave and row here -- 4 ds_swizzle per value, every input block re-read once per OUTPUT chunk -- and the
+// transform cost as much as the whole LayerNorm+quantise pass around it):
+//  * lane exchanges are DPP moves (VALU): xor 1 / xor 2 = quad_perm, xor 4 = row_half_mirror o quad_perm[3,2,1,0]
+//    (7 ^ 3), xor 8 = row_mirror o row_half_mirror (15 ^ 7);
+//  * all of a lane's chunks sit at the same position c inside their 128-blocks (chunk strides are multiples of 16), so
+//    one pass over the K input blocks feeds every output chunk of the lane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int BIT>
+__device__ __forceinline__ float lane_xor16(float v) {
+  if (BIT == 1) return dpp_mov<0xB1>(v);                  // quad_perm [1,0,3,2]
+  if (BIT == 2) return dpp_mov<0x4E>(v);                  // quad_perm [2,3,0,1]
+  if (BIT == 4) return dpp_mov<0x1B>(dpp_mov<0x141>(v));  // row_half_mirror, then quad_perm [3,2,1,0]
+  return dpp_mov<0x141>(dpp_mov<0x140>(v));               // row_mirror, then row_half_mirror
+}
+template <int BIT, int NCH>
+__device__ __forceinline__ void butterfly_lanes(float (&v)[NCH][8], int lane) {
+  const bool up = (lane & BIT) != 0;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float o = lane_xor16<BIT>(v[i][j]);
+      v[i][j] = up ? o - v[i][j] : v[i][j] + o;
+    }
+}
+
 template <int WPR, int NCH>
 __device__ __forceinline__ void hadamard_rows(float (&v)[NCH][8], const bool (&ok)[NCH], float* rowbuf, const float* hk_lds,
                                               int K, float inv_div, int lane, int sub) {
@@ -108,21 +145,11 @@ __device__ __forceinline__ void hadamard_rows(float (&v)[NCH][8], const bool (&o
           v[i][j] = a + b;
           v[i][j | h] = a - b;
         }
-#pragma unroll
-    for (int bit = 1; bit < 16; bit <<= 1) {
-      const bool up = (lane & bit) != 0;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        // lane ^ bit inside a group of 32 lanes: ds_swizzle bit mode (and 0x1f, or 0, xor bit) -- no address VGPR
-        float o;
-        if (bit == 1) o = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v[i][j]), (1 << 10) | 0x1f));
-        else if (bit == 2) o = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v[i][j]), (2 << 10) | 0x1f));
-        else if (bit == 4) o = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v[i][j]), (4 << 10) | 0x1f));
-        else o = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v[i][j]), (8 << 10) | 0x1f));
-        v[i][j] = up ? o - v[i][j] : v[i][j] + o;
-      }
-    }
   }
+  butterfly_lanes<1, NCH>(v, lane);
+  butterfly_lanes<2, NCH>(v, lane);
+  butterfly_lanes<4, NCH>(v, lane);
+  butterfly_lanes<8, NCH>(v, lane);
   if (K == 1) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
@@ -139,27 +166,35 @@ __device__ __forceinline__ void hadamard_rows(float (&v)[NCH][8], const bool (&o
       *reinterpret_cast<float4*>(dst + 4) = make_float4(v[i][4], v[i][5], v[i][6], v[i][7]);
     }
   __syncthreads();
+  const float* src = rowbuf + (lane & 15) * 8;   // position c inside every 128-block: the same for all chunks of a lane
+  const float* hrow[NCH];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i)
-    if (ok[i]) {
-      const int chunk = sub * 64 + lane + i * 64 * WPR;
-      const float* hrow = hk_lds + (chunk >> 4) * K;
-      const float* src = rowbuf + (chunk & 15) * 8;
-      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NCH; ++i) {
+    const int chunk = sub * 64 + lane + i * 64 * WPR;
+    hrow[i] = hk_lds + (ok[i] ? (chunk >> 4) : 0) * K;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+  }
 #pragma unroll 4
-      for (int k2 = 0; k2 < K; ++k2) {
-        const float sgn = hrow[k2];
-        const float4 a = *reinterpret_cast<const float4*>(src + k2 * 128);
-        const float4 b = *reinterpret_cast<const float4*>(src + k2 * 128 + 4);
-        acc[0] += sgn * a.x; acc[1] += sgn * a.y; acc[2] += sgn * a.z; acc[3] += sgn * a.w;
-        acc[4] += sgn * b.x; acc[5] += sgn * b.y; acc[6] += sgn * b.z; acc[7] += sgn * b.w;
-      }
+  for (int k2 = 0; k2 < K; ++k2) {
+    const float4 a = *reinterpret_cast<const float4*>(src + k2 * 128);
+    const float4 b = *reinterpret_cast<const float4*>(src + k2 * 128 + 4);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[i][j] = acc[j] * inv_div;
+    for (int i = 0; i < NCH; ++i) {
+      const float sgn = hrow[i][k2];
+      v[i][0] += sgn * a.x; v[i][1] += sgn * a.y; v[i][2] += sgn * a.z; v[i][3] += sgn * a.w;
+      v[i][4] += sgn * b.x; v[i][5] += sgn * b.y; v[i][6] += sgn * b.z; v[i][7] += sgn * b.w;
     }
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const float f = ok[i] ? inv_div : 0.f;  // chunks past the row end stay zero: they take part in the row max and sum
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[i][j] *= f;
+  }
 }
 
-template <int WPR, int NCH, bool LN>
+template <int WPR, int NCH, bool LN, bool MULTI = false>
 __global__ __launch_bounds__(256) void rowwise_kernel(const RowParams p) {
   __shared__ float red_slots[4 * 4];
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];  // rotation only: hadK [K*K] then row buffers
@@ -231,64 +266,91 @@ __global__ __launch_bounds__(256) void rowwise_kernel(const RowParams p) {
       for (int j = 0; j < 8; ++j) v[i][j] = gelu_tanh_f32(v[i][j]);
   }
 
-  if (p.premul) {
+  // ---- (ViDiT transform,) quantise, store: once, or once per (premul, q, scale, sum) set from the same normalised row
+  const int nsets = MULTI ? p.nsets : 1;
+  float base[MULTI ? NCH : 1][8];
+  if (MULTI) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
-      if (ok[i]) {
-        float pm[8];
-        Io<F32>::load8(p.premul, (sub * 64 + lane + i * 64 * WPR) * 8, pm);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[i][j] *= pm[j];
-      }
+      for (int j = 0; j < 8; ++j) base[i][j] = v[i][j];
   }
-  if (p.had_k) {
-    const int K = p.had_k;
-    const int kk = (K > 1) ? K * K : 0;
-    if (K > 1) {
-      for (int t = threadIdx.x; t < kk; t += 256) dyn_lds[t] = p.hadk[t];
-      __syncthreads();
+  for (int set = 0; set < nsets; ++set) {
+    const float* premul_t = p.premul;
+    int8_t* q_t = p.q;
+    void* scale_t = p.scale;
+    void* sum_t = p.sum;
+    if (MULTI && set > 0) {
+      premul_t = p.premul_n[set - 1];
+      q_t = p.q_n[set - 1];
+      scale_t = p.scale_n[set - 1];
+      sum_t = p.sum_n[set - 1];
+      __syncthreads();  // the previous set's readers of the row buffer / reduction slots are done
+#pragma unroll
+      for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] = base[i][j];
     }
-    // one row buffer per wave when a wave owns a row, one per workgroup otherwise
-    float* rowbuf = dyn_lds + ((kk + 3) & ~3) + ((WPR == 1) ? wave * C : 0);
-    hadamard_rows<WPR, NCH>(v, ok, rowbuf, dyn_lds, K, 1.0f / p.had_div, lane, sub);
-  }
+    if (premul_t) {
+  #pragma unroll
+      for (int i = 0; i < NCH; ++i)
+        if (ok[i]) {
+          float pm[8];
+          Io<F32>::load8(premul_t, (sub * 64 + lane + i * 64 * WPR) * 8, pm);
+  #pragma unroll
+          for (int j = 0; j < 8; ++j) v[i][j] *= pm[j];
+        }
+    }
+    if (p.had_k) {
+      const int K = p.had_k;
+      const int kk = (K > 1) ? K * K : 0;
+      if (K > 1 && set == 0) {
+        for (int t = threadIdx.x; t < kk; t += 256) dyn_lds[t] = p.hadk[t];
+        __syncthreads();
+      }
+      // one row buffer per wave when a wave owns a row, one per workgroup otherwise
+      float* rowbuf = dyn_lds + ((kk + 3) & ~3) + ((WPR == 1) ? wave * C : 0);
+      hadamard_rows<WPR, NCH>(v, ok, rowbuf, dyn_lds, K, 1.0f / p.had_div, lane, sub);
+    }
 
-  if (p.out_fp) {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i)
-      if (ok[i]) store8_rt(p.out_fp, p.out_dtype, rbase + (sub * 64 + lane + i * 64 * WPR) * 8, v[i]);
-  }
-  if (!p.q) return;
+    if (p.out_fp) {
+  #pragma unroll
+      for (int i = 0; i < NCH; ++i)
+        if (ok[i]) store8_rt(p.out_fp, p.out_dtype, rbase + (sub * 64 + lane + i * 64 * WPR) * 8, v[i]);
+    }
+    if (!q_t) return;
 
-  float amax;
-  if (p.static_amax) {
-    amax = dead ? 1.f : vec_load(p.scale, p.vec_dtype, row);
-  } else {
-    float m = 0.f;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[i][j]));
-    amax = red.max(m, 2);
+    float amax;
+    if (p.static_amax) {
+      amax = dead ? 1.f : vec_load(scale_t, p.vec_dtype, row);
+    } else {
+      float m = 0.f;
+  #pragma unroll
+      for (int i = 0; i < NCH; ++i)
+  #pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[i][j]));
+      amax = red.max(m, 2);
+    }
+    float scale = amax / 127.0f;
+    if (scale < 1e-6f) scale = 1e-6f;  // qdiff eps rule (base_quantizer.py:122-127)
+    const float inv = 1.0f / scale;
+    int isum = 0;
+  #pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int qi[8];
+      quant8_div_rne(v[i], scale, inv, qi);
+      const uint32_t lo = pack4_i8_fast(qi[0], qi[1], qi[2], qi[3]), hi = pack4_i8_fast(qi[4], qi[5], qi[6], qi[7]);
+      isum = __builtin_amdgcn_sdot4((int)lo, 0x01010101, isum, false);  // sum of the four signed bytes
+      isum = __builtin_amdgcn_sdot4((int)hi, 0x01010101, isum, false);
+      if (ok[i]) *reinterpret_cast<uint2*>(q_t + rbase + (sub * 64 + lane + i * 64 * WPR) * 8) = make_uint2(lo, hi);
+    }
+    if (sum_t) {
+      const int tot = red.isum(isum, 3);
+      if (lane == 0 && sub == 0 && !dead) vec_store(sum_t, p.vec_dtype, row, (float)tot * scale);
+    }
+    if (!p.static_amax && lane == 0 && sub == 0 && !dead) vec_store(scale_t, p.vec_dtype, row, scale);
+
   }
-  float scale = amax / 127.0f;
-  if (scale < 1e-6f) scale = 1e-6f;  // qdiff eps rule (base_quantizer.py:122-127)
-  const float inv = 1.0f / scale;
-  int isum = 0;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    int qi[8];
-    quant8_div_rne(v[i], scale, inv, qi);
-    const uint32_t lo = pack4_i8_fast(qi[0], qi[1], qi[2], qi[3]), hi = pack4_i8_fast(qi[4], qi[5], qi[6], qi[7]);
-    isum = __builtin_amdgcn_sdot4((int)lo, 0x01010101, isum, false);  // sum of the four signed bytes
-    isum = __builtin_amdgcn_sdot4((int)hi, 0x01010101, isum, false);
-    if (ok[i]) *reinterpret_cast<uint2*>(p.q + rbase + (sub * 64 + lane + i * 64 * WPR) * 8) = make_uint2(lo, hi);
-  }
-  if (p.sum) {
-    const int tot = red.isum(isum, 3);
-    if (lane == 0 && sub == 0 && !dead) vec_store(p.sum, p.vec_dtype, row, (float)tot * scale);
-  }
-  if (!p.static_amax && lane == 0 && sub == 0 && !dead) vec_store(p.scale, p.vec_dtype, row, scale);
 }
 
 template <bool LN>
@@ -301,8 +363,14 @@ static int launch_rowwise(const RowParams& p, hipStream_t st, const char* what) 
     dyn = (size_t)(kk + (chunks <= 256 ? 4 : 1) * p.cols) * sizeof(float);
   }
 #define WANQ_RW(WPR, NCH)                                                                       \
-  hipLaunchKernelGGL((rowwise_kernel<WPR, NCH, LN>), dim3((unsigned)((WPR) == 1 ? (rows + 3) / 4 : rows)), \
-                     dim3(256), dyn, st, p)
+  do {                                                                                          \
+    if (LN && p.nsets > 1)                                                                      \
+      hipLaunchKernelGGL((rowwise_kernel<WPR, NCH, LN, LN>), dim3((unsigned)((WPR) == 1 ? (rows + 3) / 4 : rows)), \
+                         dim3(256), dyn, st, p);                                                \
+    else                                                                                        \
+      hipLaunchKernelGGL((rowwise_kernel<WPR, NCH, LN>), dim3((unsigned)((WPR) == 1 ? (rows + 3) / 4 : rows)), \
+                         dim3(256), dyn, st, p);                                                \
+  } while (0)
   if (chunks <= 64) WANQ_RW(1, 1);
   else if (chunks <= 128) WANQ_RW(1, 2);
   else if (chunks <= 192) WANQ_RW(1, 3);
@@ -615,6 +683,36 @@ extern "C" int wanq_layernorm_rotate_quant_rows(const void* x, int x_dtype, cons
   p.vec_dtype = vec_dtype; p.rows = rows; p.cols = cols;
   p.premul = premul; p.hadk = hadk; p.had_k = had_k; p.had_div = sqrtf((float)cols);
   return launch_rowwise<true>(p, (hipStream_t)stream, "wanq_layernorm_rotate_quant_rows");
+}
+
+extern "C" int wanq_layernorm_rotate_quant_rows_multi(const void* x, int x_dtype, const void* gamma, const void* mshift,
+                                                      const void* mscale, int mod_dtype, int64_t mod_stride,
+                                                      int64_t rows_per_batch, float eps, int nsets,
+                                                      const float* const* premul, const float* hadk, int had_k,
+                                                      int8_t* const* q, void* const* scale, void* const* sum, int vec_dtype,
+                                                      int64_t rows, int cols, void* stream) {
+  const char* what = "wanq_layernorm_rotate_quant_rows_multi";
+  WANQ_REQUIRE(nsets >= 1 && nsets <= 3, WANQ_E_ARG, "%s: nsets=%d must be 1..3", what, nsets);
+  WANQ_REQUIRE(x && q && scale && sum && premul, WANQ_E_ARG, "%s: NULL pointer", what);
+  WANQ_REQUIRE(is_fp(x_dtype) && is_vec(vec_dtype), WANQ_E_ARG, "%s: bad dtype code", what);
+  WANQ_REQUIRE(!(gamma || mshift || mscale) || is_fp(mod_dtype), WANQ_E_ARG, "%s: bad mod dtype", what);
+  WANQ_REQUIRE(rows_per_batch >= 1, WANQ_E_ARG, "%s: rows_per_batch must be >= 1", what);
+  if (int e = check_rows_cols(what, rows, cols)) return e;
+  for (int t = 0; t < nsets; ++t) {
+    WANQ_REQUIRE(q[t] && scale[t], WANQ_E_ARG, "%s: set %d: q and scale are required", what, t);
+    if (int e = check_rotation(what, premul[t], hadk, had_k, cols)) return e;
+  }
+  if (rows == 0) return WANQ_OK;
+  RowParams p{};
+  p.x = x; p.x_dtype = x_dtype; p.gamma = gamma; p.mshift = mshift; p.mscale = mscale; p.mod_dtype = mod_dtype;
+  p.mod_stride = mod_stride; p.rows_per_batch = rows_per_batch; p.eps = eps; p.vec_dtype = vec_dtype; p.rows = rows; p.cols = cols;
+  p.hadk = hadk; p.had_k = had_k; p.had_div = sqrtf((float)cols);
+  p.nsets = nsets;
+  p.premul = premul[0]; p.q = q[0]; p.scale = scale[0]; p.sum = sum[0];
+  for (int t = 1; t < nsets; ++t) {
+    p.premul_n[t - 1] = premul[t]; p.q_n[t - 1] = q[t]; p.scale_n[t - 1] = scale[t]; p.sum_n[t - 1] = sum[t];
+  }
+  return launch_rowwise<true>(p, (hipStream_t)stream, what);
 }
 
 // ------------------------------------------------------------------------------ 4-bit weight storage

@@ -37,6 +37,7 @@ PROTOTYPES = {
     "wanq_rmsnorm_rope": [_vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _i64, _i64, _f, _vp],
     "wanq_rotate_quant_rows": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _vp],
     "wanq_layernorm_rotate_quant_rows": [_vp, _i, _vp, _vp, _vp, _i, _i64, _i64, _f, _vp, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _vp],
+    "wanq_layernorm_rotate_quant_rows_multi": [_vp, _i, _vp, _vp, _vp, _i, _i64, _i64, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _vp],
     "wanq_pack_w4": [_vp, _vp, _i, _i64, _i, _vp],
     "wanq_unpack_w4": [_vp, _vp, _i, _i64, _i, _vp],
     "wanq_attention_fwd": [_vp, _vp, _vp, _vp, _i, _i64, _i64, _i, _i, _i64, _i64, _i64, _i64, _f, _vp],
@@ -63,6 +64,11 @@ def dt(t_or_dtype):
 
 def ptr(t):
     return None if t is None else t.data_ptr()
+
+
+def ptr_array(tensors):
+    """Host array of device pointers (`T* const*` arguments); NULL for None entries."""
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
 
 
 def stream():

@@ -280,3 +280,46 @@ def layernorm_rotate_quant(output, input, weight, shift_msa, scale_msa, premul, 
         _C.call("wanq_layernorm_rotate_quant_rows", _C.ptr(input), _C.dt(input), _C.ptr(weight), _C.ptr(shift_msa),
                 _C.ptr(scale_msa), _C.F32, mod_stride, rows // batch, float(epsilon), _C.ptr(premul), _C.ptr(hadk), had_k,
                 _C.ptr(output), _C.ptr(scaling), _C.ptr(sum_output), _C.dt(scaling), rows, cols, _C.stream())
+
+
+def layernorm_rotate_quant_multi(outputs, input, weight, shift_msa, scale_msa, premuls, rotation, sum_outputs, scalings, epsilon):
+    """layernorm_rotate_quant for up to three consumers of the same normalised row (self-attention q / k / v): `input` is
+    read and normalised once; consumer t gets hadU(LN(input) * premuls[t]) quantised into outputs[t] / scalings[t] /
+    sum_outputs[t].  All consumers share `rotation` (same width); each has its own premul = channel_mask * signs."""
+    n = len(outputs)
+    if not (1 <= n <= 3 and len(premuls) == n and len(sum_outputs) == n and len(scalings) == n):
+        raise RuntimeError("layernorm_rotate_quant_multi: 1..3 sets, lists of equal length")
+    rows, cols = _rows_cols("input", input)
+    had_k, hadk = 0, None
+    for t in range(n):
+        had_k, hadk = _rotation_args(premuls[t], rotation, cols, input.device)
+        _C.check_gpu("output", outputs[t])
+        _C.check_dtype("output", outputs[t], torch.int8)
+        _C.check_contig("output", outputs[t])
+        _C.check_shape("output", outputs[t], rows, cols)
+        _check_vec("scaling", scalings[t], rows)
+        _check_vec("sum_output", sum_outputs[t], rows)
+        if scalings[t].dtype != scalings[0].dtype or sum_outputs[t].dtype != scalings[0].dtype:
+            raise RuntimeError("layernorm_rotate_quant_multi: scale / sum vectors must share one dtype")
+    batch, mod_stride = 1, 0
+    for m in (weight, shift_msa, scale_msa):
+        if m is not None:
+            _C.check_gpu("weight/shift/scale", m)
+            _C.check_dtype("weight/shift/scale", m, torch.float32)
+    if weight is not None:
+        _C.check_shape("weight", weight, cols)
+        weight = weight.contiguous()
+    ref = shift_msa if shift_msa is not None else scale_msa
+    if ref is not None:
+        batch = ref.shape[0]
+        mod_stride = ref.stride(0)
+        for m in (shift_msa, scale_msa):
+            if m is not None and (m.dim() != 2 or m.shape != ref.shape or m.stride(1) != 1 or m.stride(0) != mod_stride):
+                raise RuntimeError("shift_msa / scale_msa must be [batch, cols] views with equal strides")
+    with torch.cuda.device(input.device):
+        _C.call("wanq_layernorm_rotate_quant_rows_multi", _C.ptr(input), _C.dt(input), _C.ptr(weight), _C.ptr(shift_msa),
+                _C.ptr(scale_msa), _C.F32, mod_stride, rows // batch, float(epsilon), n, _C.ptr_array(premuls), _C.ptr(hadk),
+                had_k, _C.ptr_array(outputs), _C.ptr_array(scalings), _C.ptr_array(sum_outputs), _C.dt(scalings[0]), rows, cols,
+                _C.stream())
+    return outputs
+

@@ -130,6 +130,37 @@ class _LnSrc:
             self.cache[key] = (q, qs[0], qs[1])
         return self.cache[key]
 
+    def _same_rotation(self, a, b):
+        """Same Hadamard order and the same K' x K' sign matrix (a fixed function of the order: compared once, cached)."""
+        key = (id(a), id(b))
+        memo = self.blk.__dict__.setdefault("_rot_memo", {})
+        if key not in memo:
+            (ka, ha), (kb, hb) = a.rot, b.rot
+            memo[key] = ka == kb and ((ha is None and hb is None) or
+                                      (ha is not None and hb is not None and ha.shape == hb.shape and bool(torch.equal(ha, hb))))
+        return memo[key]
+
+    def prefetch(self, lins):
+        """Materialise the int8 form for several quantized consumers in ONE pass over x (q / k / v of a block share
+        this LayerNorm but carry their own ViDiT mask and rotation signs).  Falls back to the lazy per-consumer path
+        whenever the consumers do not all rotate with the same Hadamard parameters."""
+        todo = []
+        for lin in lins:
+            if not getattr(lin, "quantized", False) or lin.act_key is None or lin.act_key in self.cache or lin.rot is None:
+                continue
+            if lin.act_key not in [l.act_key for l in todo]:
+                todo.append(lin)
+        if len(todo) < 2 or not all(self._same_rotation(todo[0], l) for l in todo[1:]):
+            return
+        todo = todo[:3]
+        x, rows, C = self.x, self.x.shape[0], self.x.shape[1]
+        qs = [torch.empty(rows, C, dtype=torch.int8, device=x.device) for _ in todo]
+        vec = torch.empty(len(todo), 2, rows, dtype=torch.float32, device=x.device)
+        fused.layernorm_rotate_quant_multi(qs, x, self.gamma, self.shift, self.scale, [l.act_premul for l in todo], todo[0].rot,
+                                           [vec[i, 1] for i in range(len(todo))], [vec[i, 0] for i in range(len(todo))], self.blk.eps)
+        for i, lin in enumerate(todo):
+            self.cache[lin.act_key] = (qs[i], vec[i, 0], vec[i, 1])
+
     def fp(self):
         if "fp" not in self.cache:
             out = torch.empty(self.x.shape, dtype=self.blk.act_dtype, device=self.x.device)
@@ -237,6 +268,7 @@ class WanAttentionBlockWithHipKernel(nn.Module):
 
         # ---- self attention: LN*(1+e1)+e0 -> q,k,v -> RMSNorm+RoPE -> attention -> o (+gate, +residual)
         h = _LnSrc(self, x, None, e[:, 0], e[:, 1])
+        h.prefetch([sa.q, sa.k, sa.v])  # one pass over x for the three ViDiT-transformed int8 inputs
         q = self._linear(sa.q, h)
         ops.rmsnorm_rope_(q, sa.norm_q_weight, rope, d, eps=self.eps)
         if sp is None or sp.size == 1:
