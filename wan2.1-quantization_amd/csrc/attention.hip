@@ -360,6 +360,8 @@ extern "C" int wanq_attention_fwd(const void* q, const void* k, const void* v, v
   WANQ_REQUIRE(q_stride >= need && k_stride >= need && v_stride >= need && o_stride >= need, WANQ_E_SHAPE,
                "wanq_attention_fwd: token stride smaller than heads*head_dim");
   WANQ_REQUIRE((q_stride | k_stride | v_stride | o_stride) % 8 == 0, WANQ_E_SHAPE, "wanq_attention_fwd: strides must be multiples of 8 elements");
+  WANQ_REQUIRE(k_stride < (1ll << 24) && v_stride < (1ll << 24), WANQ_E_SHAPE,
+               "wanq_attention_fwd: k / v token stride must be below 2^24 elements (32-bit lane offsets inside a 64-key tile)");
   if (Lq == 0) return WANQ_OK;
   AttnParams p{(const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (uint16_t*)o, q_stride, k_stride, v_stride, o_stride,
                (int)Lq, (int)Lk, heads, scale * 1.4426950408889634f};
