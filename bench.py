@@ -144,9 +144,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the quantized hot path has no CPU fallback)"
+    # Rehearsal of the N > 1 control flow on a ONE-GPU box (RCCL refuses two ranks on one device): all ranks share cuda:0,
+    # rendezvous over gloo, and the collectives are staged through host memory by the test scaffolding.  Never a measurement.
+    rehearse = world > 1 and os.environ.get("WANQ_BENCH_REHEARSE_ON_ONE_GPU") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if rehearse:
+        dist.init_process_group("gloo", init_method="env://")
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from sp_rehearsal_worker import _stage_collectives
+        _stage_collectives()
+    elif world > 1:
         dist.init_process_group("nccl", init_method="env://", device_id=dev)
 
     from viditq_extension import qgemm
@@ -229,7 +239,7 @@ def main():
     qgemm.set_timer(None)
     wan_ops.set_attention_timer(None)
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
     assert torch.isfinite(latent).all(), "non-finite latent after the timed steps"
@@ -282,6 +292,8 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, seq_len)
     if rank == 0:
+        if rehearse:
+            out["data"] = "REHEARSAL on one GPU (not a measurement)"
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

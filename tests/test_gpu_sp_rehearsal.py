@@ -24,3 +24,22 @@ def test_two_ranks_on_one_gpu_match_single_rank():
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, f"rehearsal failed:\n{r.stdout[-4000:]}\n{r.stderr[-4000:]}"
     assert r.stdout.count("sp_rel=") == 2, r.stdout[-2000:]
+
+
+def test_bench_multi_rank_control_flow_rehearsal():
+    """bench.py --gpus 2 end to end (cfg-A frame count so that it takes seconds): rendezvous, parallel plan, calibration on
+    every rank, timed step with the cfg all-gather, max-over-ranks timing, one JSON line from rank 0."""
+    import json
+
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--frames", "9", "--no-cpu-baseline", "--no-quality"]
+    env = dict(os.environ, OMP_NUM_THREADS="4", WANQ_BENCH_REHEARSE_ON_ONE_GPU="1")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, f"bench rehearsal failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "cfg2xsp1" and out["value"] > 0
+    assert out["roofline"]["frac"] > 0 and "REHEARSAL" in out["data"]
