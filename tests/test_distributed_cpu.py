@@ -41,6 +41,16 @@ def _ulysses_worker(rank, world, port, q):
         assert torch.equal(s, full[0].view(L, world, -1)[:, rank])
         assert torch.equal(sp.gather_heads(s), loc[0])
         assert torch.equal(sp.gather_heads(sp.scatter_heads(loc[1], async_op=True).wait(), async_op=True).wait(), loc[1])
+        # column-chunked exchange (pipelined Ulysses): two chunks of every rank's head group, reassembled through `out`
+        cw = loc[2].shape[1] // world
+        h0 = cw // 2
+        back = torch.full_like(loc[2], float("nan"))
+        whole = sp.scatter_heads(loc[2])
+        for c0, c1 in ((0, h0), (h0, cw)):
+            part = sp.scatter_heads(loc[2], async_op=True, cols=(c0, c1)).wait()
+            assert torch.equal(part, whole[:, c0:c1])
+            sp.gather_heads(part, async_op=True, out=back, cols=(c0, c1)).wait()
+        assert torch.equal(back, loc[2])
         # Ulysses attention == full attention (key padding masked by k_len)
         k_len = L - 3
         qs, ks, vs = (sp.scatter_heads(t) for t in loc)

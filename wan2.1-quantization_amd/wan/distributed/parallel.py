@@ -9,9 +9,10 @@ What this module does, MI355X-first:
   * Ulysses: every token-local op (LN/quant, all GEMMs, cross-attention, FFN) runs on a [L/P, C] shard; per
     self-attention q, k, v go through ONE all-to-all each (head-scatter / sequence-gather, rank order ==
     sequence order so the per-rank RoPE slice stays valid), attention runs on H/P heads over the full
-    sequence, and one all-to-all brings the output back.  The three forward all-to-alls are issued async
-    (they run on the process group's own HIP stream) so that the k / v GEMMs and RMSNorm+RoPE kernels overlap
-    the q / k transfers; xGMI is point-to-point, so an all-to-all drives all links at once.
+    sequence, and one all-to-all brings the output back.  The exchanges are pipelined over two head chunks
+    (wan/quant_wanx_hip.py): all of them are issued async (they run on the process group's own HIP stream, in issue
+    order), chunk 0 of q / k / v flies under the k / v GEMMs, chunk 1 and the way back of chunk 0 under the
+    attention of the other chunk; xGMI is point-to-point, so an all-to-all drives all links at once.
   * CFG parallelism: the conditional and unconditional passes of a step are independent until the guidance
     combine, so with an even number of GPUs half of them run each pass (no per-block communication at all)
     and one 2 MB all-gather per step joins them.  1.3B has 12 heads, so Ulysses alone cannot use 8 GPUs
@@ -66,29 +67,47 @@ class SeqParallel:
         return out
 
     # ---- head-scatter / sequence-gather all-to-all and its inverse ---------------------------------
-    def scatter_heads(self, x, async_op=False):
-        """[Lp, C] (all heads, local tokens) -> [P*Lp, C/P] (this rank's head group, all tokens)."""
+    # `cols=(c0, c1)` restricts the exchange to columns c0..c1 of every rank's head group (a whole number of heads): the block
+    # pipelines the exchange of one head chunk under the attention of the previous one.
+    def scatter_heads(self, x, async_op=False, cols=None):
+        """[Lp, C] (all heads, local tokens) -> [P*Lp, w] (this rank's head group -- or its column slice -- all tokens)."""
         P = self.size
         if P == 1:
-            return _Done(x) if async_op else x
+            y = x if cols is None else x[:, cols[0]:cols[1]]
+            return _Done(y) if async_op else y
         lp, c = x.shape
-        send = x.view(lp, P, c // P).transpose(0, 1).contiguous()  # [P, Lp, C/P]: block r goes to rank r
+        send = x.view(lp, P, c // P)
+        if cols is not None:
+            send = send[:, :, cols[0]:cols[1]]
+        w = send.shape[2]
+        send = send.transpose(0, 1).contiguous()  # [P, Lp, w]: block r goes to rank r
         recv = torch.empty_like(send)
         work = dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)
-        post = lambda r: r.view(P * lp, c // P)  # noqa: E731  blocks arrive in rank order == sequence order
+        post = lambda r: r.view(P * lp, w)  # noqa: E731  blocks arrive in rank order == sequence order
         return _Pending(work, recv, post) if async_op else post(recv)
 
-    def gather_heads(self, x, async_op=False):
-        """[P*Lp, C/P] -> [Lp, C]: inverse of scatter_heads."""
+    def gather_heads(self, x, async_op=False, out=None, cols=None):
+        """[P*Lp, w] -> [Lp, P*w]: inverse of scatter_heads.  With `out` ([Lp, C]) and `cols` the chunk lands in columns
+        c0..c1 of every head group of `out` (which is returned)."""
         P = self.size
         if P == 1:
-            return _Done(x) if async_op else x
-        l, cp = x.shape
+            if out is None:
+                return _Done(x) if async_op else x
+            out[:, cols[0]:cols[1]] = x
+            return _Done(out) if async_op else out
+        l, w = x.shape
         lp = l // P
-        send = x.contiguous().view(P, lp, cp)  # block r = tokens of rank r
+        send = x.contiguous().view(P, lp, w)  # block r = tokens of rank r
         recv = torch.empty_like(send)
         work = dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)
-        post = lambda r: r.transpose(0, 1).reshape(lp, P * cp)  # noqa: E731  block s = head group s
+        if out is None:
+            post = lambda r: r.transpose(0, 1).reshape(lp, P * w)  # noqa: E731  block s = head group s
+        else:
+            c0, c1 = cols
+
+            def post(r):
+                out.view(lp, P, out.shape[1] // P)[:, :, c0:c1] = r.transpose(0, 1)
+                return out
         return _Pending(work, recv, post) if async_op else post(recv)
 
 

@@ -276,15 +276,28 @@ class WanAttentionBlockWithHipKernel(nn.Module):
             ops.rmsnorm_rope_(k, sa.norm_k_weight, rope, d, eps=self.eps)
             v = self._linear(sa.v, h)
             o = ops.attention(q, k, v, H, seq_len)
-        else:  # Ulysses: the q / k all-to-alls fly under the k / v GEMMs
-            wq = sp.scatter_heads(q, async_op=True)
+        else:
+            # Ulysses, pipelined over head chunks: this rank's H/P heads are split in two; the exchange of chunk 1 (and the
+            # way back of chunk 0) flies under the attention of the other chunk, so about half of the all-to-all time of a
+            # block hides behind its 2-6 ms of attention.  The collectives run in issue order on the group's own stream.
+            hl = H // sp.size
+            h0 = (hl + 1) // 2
+            chunks = [(0, h0 * d)] + ([(h0 * d, hl * d)] if hl > h0 else [])
+            pend = [[sp.scatter_heads(q, async_op=True, cols=chunks[0])]]      # chunk 0 of q flies under the k GEMM
             k = self._linear(sa.k, h)
             ops.rmsnorm_rope_(k, sa.norm_k_weight, rope, d, eps=self.eps)
-            wk = sp.scatter_heads(k, async_op=True)
+            pend[0].append(sp.scatter_heads(k, async_op=True, cols=chunks[0]))  # ... of k under the v GEMM
             v = self._linear(sa.v, h)
-            wv = sp.scatter_heads(v, async_op=True)
-            o = ops.attention(wq.wait(), wk.wait(), wv.wait(), H // sp.size, seq_len)
-            o = sp.gather_heads(o)
+            pend[0].append(sp.scatter_heads(v, async_op=True, cols=chunks[0]))
+            for cw in chunks[1:]:
+                pend.append([sp.scatter_heads(t, async_op=True, cols=cw) for t in (q, k, v)])
+            o = torch.empty_like(q)
+            back = []
+            for (c0, c1), (wq, wk, wv) in zip(chunks, pend):
+                oc = ops.attention(wq.wait(), wk.wait(), wv.wait(), (c1 - c0) // d, seq_len)
+                back.append(sp.gather_heads(oc, async_op=True, out=o, cols=(c0, c1)))
+            for b in back:
+                b.wait()
         self._linear(sa.o, _FpSrc(o), gate=e[0, 2].contiguous(), residual=x)
 
         # ---- cross attention: LN_affine -> q; k,v from the text context
