@@ -93,7 +93,10 @@ def main():
     def rel(a, b):
         return ((a - b).norm() / b.norm()).item()
 
-    # ---- Ulysses over both ranks (cfg 1 x sp 2)
+    # ---- Ulysses over both ranks (cfg 1 x sp 2), with the head-chunked exchange pipeline forced on (2 local heads -> 1 + 1)
+    import wan.quant_wanx_hip as qh
+    qh._FORCE_CHUNK_UNIT = 1
+    assert len(qh._head_chunks(2, 270, dev)) == 2
     plan = ParallelPlan(world, rank, 1, world)
     assert plan.sp.size == world
     sl = seq_len_for(shape, sp_size=world)

@@ -194,6 +194,35 @@ class _FpSrc:
         return self.t
 
 
+_N_CU = {}
+_FORCE_CHUNK_UNIT = None  # tests: pipeline the exchange even when a tiny model's heads do not fill a GPU round
+
+
+def _head_chunks(heads, seq_len, device, max_chunks=4):
+    """Split a rank's `heads` for the pipelined Ulysses exchange.  The attention kernel launches ceil(L/256) workgroups per
+    head, one per CU at a time, so a chunk should fill whole rounds of the GPU: with L = 32760 (128 workgroups per head,
+    256 CUs) chunks are multiples of 2 heads -- 6 heads -> (2, 2, 2), never (3, 3), which would run 4 half-empty rounds
+    instead of 3 full ones.  Small chunks first and last: those are the exchanges nothing hides."""
+    if device not in _N_CU:
+        _N_CU[device] = torch.cuda.get_device_properties(device).multi_processor_count if device.type == "cuda" else 256
+    per_head = -(-seq_len // 256)
+    unit = _FORCE_CHUNK_UNIT or max(1, _N_CU[device] // per_head)   # heads per full round of the GPU (>= 1)
+    units, rem = divmod(heads, unit)
+    n = min(max_chunks - (1 if rem else 0), units)
+    if n <= 0:
+        return [(0, heads)]
+    sizes = [units // n * unit] * n
+    for i in range(units % n):               # spare whole units go to the middle chunks
+        sizes[(n // 2 + i) % n] += unit
+    if rem:
+        sizes.append(rem)                    # a last, smaller chunk: its partial round exists either way
+    out, a = [], 0
+    for sz in sizes:
+        out.append((a, a + sz))
+        a += sz
+    return out if len(out) > 1 else [(0, heads)]
+
+
 class _Attn(nn.Module):
     def __init__(self, dim):
         super().__init__()
@@ -280,9 +309,7 @@ class WanAttentionBlockWithHipKernel(nn.Module):
             # Ulysses, pipelined over head chunks: this rank's H/P heads are split in two; the exchange of chunk 1 (and the
             # way back of chunk 0) flies under the attention of the other chunk, so about half of the all-to-all time of a
             # block hides behind its 2-6 ms of attention.  The collectives run in issue order on the group's own stream.
-            hl = H // sp.size
-            h0 = (hl + 1) // 2
-            chunks = [(0, h0 * d)] + ([(h0 * d, hl * d)] if hl > h0 else [])
+            chunks = [(a * d, b * d) for a, b in _head_chunks(H // sp.size, q.shape[0] * sp.size, q.device)]
             pend = [[sp.scatter_heads(q, async_op=True, cols=chunks[0])]]      # chunk 0 of q flies under the k GEMM
             k = self._linear(sa.k, h)
             ops.rmsnorm_rope_(k, sa.norm_k_weight, rope, d, eps=self.eps)
