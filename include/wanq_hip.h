@@ -138,6 +138,18 @@ int wanq_attention_fwd(const void* q, const void* k, const void* v, void* o, int
                        int64_t Lk, int heads, int head_dim, int64_t q_stride, int64_t k_stride,
                        int64_t v_stride, int64_t o_stride, float scale, void* stream);
 
+/* The same with the keys split over `splits` workgroups per (query block, head) ("split-KV"): every share writes
+ * unnormalised fp32 partials (O, reference maximum, row sum) into `workspace` and a second kernel merges them.  For launches
+ * whose (query blocks x heads) grid leaves a large part of the last round of CUs idle -- 3 heads x 128 query blocks on 256
+ * CUs under 4-way sequence parallelism: 1.5 rounds cost 2 -- halving the work unit restores the balance.
+ * wanq_attention_split_workspace() gives the bytes `workspace` (16-byte aligned, device memory) must hold; splits <= 1 or
+ * more splits than 64-key tiles fall back to fewer.  No counterpart in the reference (flash_attn picks its own splits). */
+int64_t wanq_attention_split_workspace(int64_t Lq, int heads, int head_dim, int splits);
+int wanq_attention_fwd_split(const void* q, const void* k, const void* v, void* o, int dtype, int64_t Lq,
+                             int64_t Lk, int heads, int head_dim, int64_t q_stride, int64_t k_stride,
+                             int64_t v_stride, int64_t o_stride, float scale, int splits, void* workspace,
+                             int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * ViDiT activation transform fused with the per-token quantiser:
  *   y = hadU(x * premul),   hadU = (H_K (x) H_128) / sqrt(cols)   (natural-order Walsh-Hadamard on each

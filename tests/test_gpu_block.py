@@ -134,6 +134,36 @@ def test_flash_attention_vs_fp32_softmax(Lq, Lk, H, klen):
     assert rel_err(out.float().cpu(), ref) < 1e-2
 
 
+@pytest.mark.parametrize("Lq,Lk,H,klen,splits", [(300, 2100, 2, None, 2), (257, 2500, 1, 2437, 3), (64, 4096, 3, None, 4), (500, 130, 2, None, 5)])
+def test_flash_attention_split_kv_matches_unsplit_and_fp32(Lq, Lk, H, klen, splits):
+    """Split-KV (partials + merge kernel): same result as one workgroup per (query block, head) up to the fp32 merge order,
+    and within the usual tolerance of the fp32 definition; ragged last tile in the last share, more splits than tiles."""
+    from wan import ops
+
+    d = 128
+    g = torch.Generator().manual_seed(Lq + Lk + splits)
+    q = (torch.randn(Lq, H * d, generator=g) * 1.5).to(torch.bfloat16).to(DEV)
+    k = (torch.randn(Lk, H * d, generator=g) * 1.5).to(torch.bfloat16).to(DEV)
+    v = torch.randn(Lk, H * d, generator=g).to(torch.bfloat16).to(DEV)
+    k[Lk // 2 + 5] *= 4.0  # a dominant key in a later share: the merge must rescale the earlier partials
+    one = ops.attention(q, k, v, H, klen, splits=1)
+    many = ops.attention(q, k, v, H, klen, splits=splits)
+    assert float((many.float() - one.float()).abs().max()) <= 2.0 ** -7 * float(one.float().abs().max())  # one bf16 rounding apart
+    ref = wr.attention(q.float().cpu().view(Lq, H, d), k.float().cpu().view(Lk, H, d), v.float().cpu().view(Lk, H, d), klen).reshape(Lq, H * d)
+    assert (many.float().cpu() - ref).abs().max().item() < 3e-2 and rel_err(many.float().cpu(), ref) < 1e-2
+
+
+def test_attention_split_heuristic():
+    from wan import ops
+
+    dev = torch.device(DEV)
+    assert ops.attention_splits(32760, 32760, 12, dev) == 1   # 1536 workgroups: 6 full rounds of 256 CUs
+    assert ops.attention_splits(32760, 32760, 6, dev) == 1    # 3 full rounds
+    assert ops.attention_splits(32760, 32760, 3, dev) == 2    # 1.5 rounds would cost 2
+    assert ops.attention_splits(32760, 32760, 1, dev) >= 2    # one head alone fills half the GPU
+    assert ops.attention_splits(32760, 512, 12, dev) == 1     # cross-attention: nothing to share
+
+
 def test_flash_attention_strided_views_of_packed_qkv():
     from wan import ops
 

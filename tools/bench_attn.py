@@ -32,3 +32,14 @@ for (Lq, Lk, H) in [(32760, 32760, 12), (32760, 512, 12), (9450, 75600, 5)]:
     print(f"hip  attention Lq={Lq} Lk={Lk} H={H}: {t*1e3:8.3f} ms {fl/t/1e12:7.1f} TFLOPS ({fl/t/2.5e15*100:.1f}% of bf16 MFMA peak)")
     t = timeit(lambda: ops.attention_sdpa(q, k, v, H))
     print(f"sdpa attention Lq={Lq} Lk={Lk} H={H}: {t*1e3:8.3f} ms {fl/t/1e12:7.1f} TFLOPS")
+
+# the per-rank shape under 4-way sequence parallelism (3 of 12 heads, all 32760 tokens): 384 workgroups on 256 CUs
+Lq = Lk = 32760
+for H in (3, 1):
+    q = torch.randn(Lq, H * 128, device="cuda").to(torch.bfloat16)
+    k = torch.randn(Lk, H * 128, device="cuda").to(torch.bfloat16)
+    v = torch.randn(Lk, H * 128, device="cuda").to(torch.bfloat16)
+    fl = 4.0 * Lq * Lk * 128 * H
+    for s in (1, 2):
+        t = timeit(lambda: ops.attention(q, k, v, H, splits=s))
+        print(f"hip  attention Lq={Lq} Lk={Lk} H={H} splits={s}: {t*1e3:8.3f} ms {fl/t/1e12:7.1f} TFLOPS")

@@ -36,6 +36,10 @@ struct AttnParams {
   int64_t q_stride, k_stride, v_stride, o_stride;  // elements between consecutive tokens
   int Lq, Lk, H;
   float c;  // softmax scale * log2(e)
+  // split-KV (gridDim.z > 1): workgroup z covers key tiles [z*tiles_per_split, ...) and writes unnormalised partials
+  int tiles_per_split;
+  float* part_o;   // [splits, Lq, H*128] fp32: O^T accumulators relative to the split's reference maximum
+  float* part_ml;  // [splits, Lq, H, 2]  fp32: (reference maximum m, row sum l)
 };
 
 constexpr int AT_D = 128, AT_QW = 32, AT_NW = 8, AT_QB = AT_QW * AT_NW, AT_KB = 64;
@@ -52,7 +56,7 @@ __device__ __forceinline__ bf16x8 at_join(s16x4 lo, s16x4 hi) {
   return __builtin_bit_cast(bf16x8, vv);
 }
 
-template <bool DMA>
+template <bool DMA, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -61,6 +65,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
   const int q0 = blockIdx.x * AT_QB + wave * AT_QW;
   const int nt = (p.Lk + AT_KB - 1) / AT_KB;
   const float c = p.c;
+  // key tiles of this workgroup: all of them, or one contiguous share under split-KV (the host makes every share non-empty)
+  const int jt0 = SPLIT ? (int)blockIdx.z * p.tiles_per_split : 0;
+  const int jt1 = SPLIT ? (jt0 + p.tiles_per_split < nt ? jt0 + p.tiles_per_split : nt) : nt;
 
   // ---- Q fragments: query (q0+fr), d = 16 s + 8 fh + [0,8)
   bf16x8 qf[8];
@@ -154,9 +161,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
   float m_run = -INFINITY, l_run = 0.f;
 
   if (DMA) {
-    AT_DMA(0, 0);
-    if (nt > 1) {
-      AT_DMA(1, 1);
+    AT_DMA(jt0, 0);
+    if (jt0 + 1 < jt1) {
+      AT_DMA(jt0 + 1, 1);
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -169,15 +176,15 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     __syncthreads();
   }
 
-  int st3 = 0;  // DMA: ring of three stages, j % 3
-  for (int j = 0; j < nt; ++j) {
+  int st3 = 0;  // DMA: ring of three stages, (j - jt0) % 3
+  for (int j = jt0; j < jt1; ++j) {
     const int cur = DMA ? st3 : (j & 1);
     const char* sK = smem + cur * AT_STAGE;
     const char* sV = sK + AT_TILE;
     // every wave is past the barrier that ended tile j-1, so the stage that held it is free: tile j+2 goes there and has
     // two tile-times to land
     const int st_free = st3 == 0 ? 2 : st3 - 1;
-    if (DMA && j + 2 < nt) AT_DMA(j + 2, st_free);
+    if (DMA && j + 2 < jt1) AT_DMA(j + 2, st_free);
 
     // ---------------- S^T = K . Q^T  (two 32-key blocks)
     f32x16 s0, s1;
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     }
     if (DMA) {
       // tile j+1 must have landed; the four instructions of tile j+2 (if issued) may stay in flight
-      if (j + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (j + 2 < jt1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       st3 = st3 == 2 ? 0 : st3 + 1;
       __builtin_amdgcn_s_barrier();  // bare: __syncthreads() would drain vmcnt to 0 and with it the prefetch
@@ -327,6 +334,23 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
 
   // ---- epilogue: O[q, d] = O^T[d, q] / l ; lane holds d = 32 db + (r&3) + 8 (r>>2) + 4 fh of query fr
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (SPLIT) {  // unnormalised partials; attn_combine_kernel merges the splits
+    const int qr = q0 + fr;
+    if (qr < p.Lq) {
+      float* po = p.part_o + ((int64_t)blockIdx.z * p.Lq + qr) * (p.H * AT_D) + head * AT_D + 4 * fh;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(po + 32 * db + 8 * g) = make_float4(o[db][4 * g], o[db][4 * g + 1], o[db][4 * g + 2], o[db][4 * g + 3]);
+      if (fh == 0) {
+        float* pm = p.part_ml + (((int64_t)blockIdx.z * p.Lq + qr) * p.H + head) * 2;
+        pm[0] = m_run;
+        pm[1] = l_tot;
+      }
+    }
+    return;
+  }
   const float inv = 1.0f / l_tot;
   const int qr = q0 + fr;
   if (qr < p.Lq) {
@@ -344,13 +368,40 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
   }
 }
 
+// Split-KV merge: out[q, h, :] = sum_z w_z O_z / sum_z w_z l_z,  w_z = 2^{(m_z - max_z m_z) c}.  One thread per 4 channels.
+__global__ __launch_bounds__(256) void attn_combine_kernel(const AttnParams p, int splits) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int per_q = p.H * (AT_D / 4);
+  const int64_t q = t / per_q;
+  if (q >= p.Lq) return;
+  const int r = (int)(t - q * per_q), h = r / (AT_D / 4), d4 = r % (AT_D / 4);
+  float M = -INFINITY;
+  for (int z = 0; z < splits; ++z) M = fmaxf(M, p.part_ml[(((int64_t)z * p.Lq + q) * p.H + h) * 2]);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float l = 0.f;
+  for (int z = 0; z < splits; ++z) {
+    const float* ml = p.part_ml + (((int64_t)z * p.Lq + q) * p.H + h) * 2;
+    const float w = __builtin_amdgcn_exp2f((ml[0] - M) * p.c);
+    const float4 v = *reinterpret_cast<const float4*>(p.part_o + ((int64_t)z * p.Lq + q) * (p.H * AT_D) + h * AT_D + 4 * d4);
+    acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+    l += w * ml[1];
+  }
+  const float inv = 1.0f / l;
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  bf16x4 b;
+  b[0] = (__bf16)(acc.x * inv); b[1] = (__bf16)(acc.y * inv); b[2] = (__bf16)(acc.z * inv); b[3] = (__bf16)(acc.w * inv);
+  *reinterpret_cast<bf16x4*>(p.o + q * p.o_stride + h * AT_D + 4 * d4) = b;
+}
+
 }  // namespace wanq
 
 using namespace wanq;
 
-extern "C" int wanq_attention_fwd(const void* q, const void* k, const void* v, void* o, int dtype, int64_t Lq,
-                                  int64_t Lk, int heads, int head_dim, int64_t q_stride, int64_t k_stride,
-                                  int64_t v_stride, int64_t o_stride, float scale, void* stream) {
+extern "C" int64_t wanq_attention_split_workspace(int64_t Lq, int heads, int head_dim, int splits);
+
+static int attention_impl(const void* q, const void* k, const void* v, void* o, int dtype, int64_t Lq, int64_t Lk, int heads,
+                          int head_dim, int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride, float scale,
+                          int splits, void* workspace, int64_t workspace_bytes, void* stream) {
   WANQ_REQUIRE(q && k && v && o, WANQ_E_ARG, "wanq_attention_fwd: NULL pointer");
   WANQ_REQUIRE(dtype == WANQ_BF16, WANQ_E_ARG, "wanq_attention_fwd: only bf16 is implemented (dtype code %d)", dtype);
   WANQ_REQUIRE(head_dim == AT_D, WANQ_E_SHAPE, "wanq_attention_fwd: head_dim=%d, only 128 is implemented", head_dim);
@@ -375,7 +426,51 @@ extern "C" int wanq_attention_fwd(const void* q, const void* k, const void* v, v
     attr_set = true;
   }
   dim3 grid((unsigned)((Lq + AT_QB - 1) / AT_QB), (unsigned)heads);
-  if (v1) hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(512), 2 * AT_STAGE, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(512), 3 * AT_STAGE, (hipStream_t)stream, p);
-  return check_launch("wanq_attention_fwd");
+  const int nt = (int)((Lk + AT_KB - 1) / AT_KB);
+  if (splits > nt) splits = nt;
+  if (splits > 1) {
+    p.tiles_per_split = (nt + splits - 1) / splits;
+    splits = (nt + p.tiles_per_split - 1) / p.tiles_per_split;  // no empty share
+  }
+  if (splits <= 1) {
+    if (v1) hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(512), 2 * AT_STAGE, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(512), 3 * AT_STAGE, (hipStream_t)stream, p);
+    return check_launch("wanq_attention_fwd");
+  }
+  const int64_t need_ws = wanq_attention_split_workspace(Lq, heads, head_dim, splits);
+  WANQ_REQUIRE(workspace && workspace_bytes >= need_ws, WANQ_E_ARG,
+               "wanq_attention_fwd_split: workspace of %lld bytes needed, %lld given", (long long)need_ws, (long long)workspace_bytes);
+  WANQ_REQUIRE(((uintptr_t)workspace & 15) == 0, WANQ_E_ARG, "wanq_attention_fwd_split: workspace must be 16-byte aligned");
+  p.part_o = static_cast<float*>(workspace);
+  p.part_ml = p.part_o + (int64_t)splits * Lq * heads * AT_D;
+  static bool attr_split = false;
+  if (!attr_split) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * AT_STAGE);
+    attr_split = true;
+  }
+  grid.z = (unsigned)splits;
+  hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, dim3(512), 3 * AT_STAGE, (hipStream_t)stream, p);
+  const int64_t threads = Lq * heads * (AT_D / 4);
+  hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, splits);
+  return check_launch("wanq_attention_fwd_split");
+}
+
+extern "C" int64_t wanq_attention_split_workspace(int64_t Lq, int heads, int head_dim, int splits) {
+  if (splits <= 1) return 0;
+  return (int64_t)splits * Lq * heads * (head_dim + 2) * (int64_t)sizeof(float);
+}
+
+extern "C" int wanq_attention_fwd(const void* q, const void* k, const void* v, void* o, int dtype, int64_t Lq,
+                                  int64_t Lk, int heads, int head_dim, int64_t q_stride, int64_t k_stride,
+                                  int64_t v_stride, int64_t o_stride, float scale, void* stream) {
+  return attention_impl(q, k, v, o, dtype, Lq, Lk, heads, head_dim, q_stride, k_stride, v_stride, o_stride, scale, 1, nullptr, 0, stream);
+}
+
+extern "C" int wanq_attention_fwd_split(const void* q, const void* k, const void* v, void* o, int dtype, int64_t Lq,
+                                        int64_t Lk, int heads, int head_dim, int64_t q_stride, int64_t k_stride,
+                                        int64_t v_stride, int64_t o_stride, float scale, int splits, void* workspace,
+                                        int64_t workspace_bytes, void* stream) {
+  WANQ_REQUIRE(splits >= 1 && splits <= 64, WANQ_E_ARG, "wanq_attention_fwd_split: splits=%d must be 1..64", splits);
+  return attention_impl(q, k, v, o, dtype, Lq, Lk, heads, head_dim, q_stride, k_stride, v_stride, o_stride, scale, splits, workspace,
+                        workspace_bytes, stream);
 }

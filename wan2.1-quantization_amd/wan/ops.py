@@ -50,10 +50,30 @@ def set_attention_timer(t):
     _attn_timer = t
 
 
-def attention(q, k, v, num_heads, k_len=None, out=None):
+_N_CU = {}
+
+
+def attention_splits(Lq, Lk, num_heads, device):
+    """Key splits for wanq_attention_fwd_split: > 1 only when (query blocks x heads) leaves much of the last round of CUs idle
+    and the key sequence is long enough to share (e.g. 3 heads x 128 blocks on 256 CUs: 1.5 rounds cost 2 -> split 2)."""
+    if device not in _N_CU:
+        _N_CU[device] = torch.cuda.get_device_properties(device).multi_processor_count
+    ncu, blocks, tiles = _N_CU[device], -(-Lq // 256) * num_heads, -(-Lk // 64)
+    if tiles < 32:
+        return 1
+    best, cost = 1, float(-(-blocks // ncu))
+    for s in (2, 3, 4):
+        c = -(-(blocks * s) // ncu) / s * 1.03  # partial write-out + merge
+        if c < cost * 0.93:
+            best, cost = s, c
+    return best
+
+
+def attention(q, k, v, num_heads, k_len=None, out=None, splits=None):
     """softmax(q k^T / sqrt(d)) v for one sample on the HIP flash-attention kernel (csrc/attention.hip).
     q [Lq, C], k/v [Lk, C] bf16, token-major (row stride may exceed C: column slices of a packed buffer are
-    fine) -> [Lq, C].  k_len masks key padding (flash_attention(..., k_lens), wan/modules/attention.py:78-80)."""
+    fine) -> [Lq, C].  k_len masks key padding (flash_attention(..., k_lens), wan/modules/attention.py:78-80).
+    splits: None = attention_splits() decides; 1 = one workgroup per (query block, head); n = split-KV."""
     Lq, C = q.shape
     d = C // num_heads
     for n, t in (("q", q), ("k", k), ("v", v)):
@@ -66,12 +86,21 @@ def attention(q, k, v, num_heads, k_len=None, out=None):
     Lk = k.shape[0] if k_len is None else min(int(k_len), k.shape[0])
     if out is None:
         out = torch.empty(Lq, C, dtype=q.dtype, device=q.device)
+    if splits is None:
+        splits = attention_splits(Lq, Lk, num_heads, q.device)
     with torch.cuda.device(q.device):
         if _attn_timer is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        _C.call("wanq_attention_fwd", _C.ptr(q), _C.ptr(k), _C.ptr(v), _C.ptr(out), _C.dt(q), Lq, Lk, num_heads, d,
-                q.stride(0), k.stride(0), v.stride(0), out.stride(0), 1.0 / math.sqrt(d), _C.stream())
+        if splits <= 1:
+            _C.call("wanq_attention_fwd", _C.ptr(q), _C.ptr(k), _C.ptr(v), _C.ptr(out), _C.dt(q), Lq, Lk, num_heads, d,
+                    q.stride(0), k.stride(0), v.stride(0), out.stride(0), 1.0 / math.sqrt(d), _C.stream())
+        else:
+            nbytes = _C.lib.wanq_attention_split_workspace(Lq, num_heads, d, int(splits))
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=q.device)
+            _C.call("wanq_attention_fwd_split", _C.ptr(q), _C.ptr(k), _C.ptr(v), _C.ptr(out), _C.dt(q), Lq, Lk, num_heads, d,
+                    q.stride(0), k.stride(0), v.stride(0), out.stride(0), 1.0 / math.sqrt(d), int(splits), _C.ptr(ws), nbytes,
+                    _C.stream())
         if _attn_timer is not None:
             ev1.record()
             _attn_timer.append((ev0, ev1, 4 * Lq * Lk * d * num_heads))
