@@ -56,6 +56,13 @@ __device__ __forceinline__ bf16x8 at_join(s16x4 lo, s16x4 hi) {
   return __builtin_bit_cast(bf16x8, vv);
 }
 
+#ifdef WANQ_ATTN_STAMP
+__device__ unsigned long long g_stamp[8 * 16];
+#define STAMP(i) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); acc_[i] += t_ - last_; last_ = t_; }
+#else
+#define STAMP(i)
+#endif
+
 template <bool DMA, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -176,6 +183,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     __syncthreads();
   }
 
+#ifdef WANQ_ATTN_STAMP
+  unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_) :: "memory");
+#endif
   int st3 = 0;  // DMA: ring of three stages, (j - jt0) % 3
   for (int j = jt0; j < jt1; ++j) {
     const int cur = DMA ? st3 : (j & 1);
@@ -185,6 +196,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     // two tile-times to land
     const int st_free = st3 == 0 ? 2 : st3 - 1;
     if (DMA && j + 2 < jt1) AT_DMA(j + 2, st_free);
+    STAMP(0)
 
     // ---------------- S^T = K . Q^T  (two 32-key blocks)
     f32x16 s0, s1;
@@ -217,6 +229,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
         s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s], s1, 0, 0, 0);
       }
     }
+    STAMP(1)
     if (j == nt - 1 && (p.Lk & (AT_KB - 1))) {  // ragged last tile: keys >= Lk get -inf
       const int kb = j * AT_KB + 4 * fh;
 #pragma unroll
@@ -266,6 +279,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
       pf[3][e] = (__bf16)s1[8 + e];
     }
 
+    STAMP(2)
     // ---------------- next tile: registers -> other LDS stage, then fetch the tile after it
     if (!DMA && j + 1 < nt) {
       AT_LSTORE(cur ^ 1);
@@ -321,16 +335,24 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
         }
       }
     }
+    STAMP(3)
     if (DMA) {
       // tile j+1 must have landed; the four instructions of tile j+2 (if issued) may stay in flight
       if (j + 2 < jt1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       st3 = st3 == 2 ? 0 : st3 + 1;
+      STAMP(4)
       __builtin_amdgcn_s_barrier();  // bare: __syncthreads() would drain vmcnt to 0 and with it the prefetch
     } else {
       __syncthreads();
     }
+    STAMP(5)
   }
+#ifdef WANQ_ATTN_STAMP
+  if (blockIdx.x == 7 && blockIdx.y == 3 && lane == 0) {
+    for (int i = 0; i < 6; ++i) g_stamp[wave * 16 + i] = acc_[i];
+  }
+#endif
 
   // ---- epilogue: O[q, d] = O^T[d, q] / l ; lane holds d = 32 db + (r&3) + 8 (r>>2) + 4 fh of query fr
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -435,6 +457,17 @@ static int attention_impl(const void* q, const void* k, const void* v, void* o, 
   if (splits <= 1) {
     if (v1) hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(512), 2 * AT_STAGE, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(512), 3 * AT_STAGE, (hipStream_t)stream, p);
+#ifdef WANQ_ATTN_STAMP
+    {
+      (void)hipStreamSynchronize((hipStream_t)stream);
+      unsigned long long h[8 * 16];
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp), sizeof(h));
+      const char* names[6] = {"dma issue", "S = K.Q^T", "softmax", "PV", "vmcnt wait", "barrier"};
+      printf("[stamp] Lq=%lld Lk=%lld tiles=%d: s_memtime ticks per tile, waves 0 / 3 / 4 / 7\n", (long long)Lq, (long long)Lk, nt);
+      for (int i = 0; i < 6; ++i)
+        printf("[stamp] %-10s %8.1f %8.1f %8.1f %8.1f\n", names[i], (double)h[0 * 16 + i] / nt, (double)h[3 * 16 + i] / nt, (double)h[4 * 16 + i] / nt, (double)h[7 * 16 + i] / nt);
+    }
+#endif
     return check_launch("wanq_attention_fwd");
   }
   const int64_t need_ws = wanq_attention_split_workspace(Lq, heads, head_dim, splits);
