@@ -139,3 +139,24 @@ def test_plan_choice_rules():
     assert ParallelPlan.choose(8, 40) == (2, 4)
     with pytest.raises(ValueError):
         ParallelPlan.choose(8, 12, cfg_parallel=False)
+
+
+def test_head_chunks_and_split_kv_policy():
+    """Host policy of the pipelined Ulysses exchange and of split-KV attention (no GPU): chunks tile the rank's heads, are
+    whole rounds of the 256 CUs where a head is 128 workgroups, and split-KV turns on exactly for half-empty last rounds."""
+    from wan import ops
+    from wan.quant_wanx_hip import _head_chunks
+
+    cpu = torch.device("cpu")  # _head_chunks assumes 256 CUs off-GPU
+    for heads, L in [(6, 32760), (3, 32760), (12, 32760), (5, 75600), (20, 75600), (10, 75600), (2, 192), (1, 192), (6, 4680)]:
+        ch = _head_chunks(heads, L, cpu)
+        assert ch[0][0] == 0 and ch[-1][1] == heads and all(a[1] == b[0] and a[1] > a[0] for a, b in zip(ch, ch[1:])) and len(ch) <= 4
+    assert _head_chunks(6, 32760, cpu) == [(0, 2), (2, 4), (4, 6)]   # never 3 + 3: two half-empty rounds each
+    assert _head_chunks(3, 32760, cpu) == [(0, 2), (2, 3)]
+    assert _head_chunks(6, 4680, cpu) == [(0, 6)]                    # 6 heads x 19 workgroups do not even fill one round
+    assert ops.attention_splits(32760, 32760, 12, cpu, ncu=256) == 1
+    assert ops.attention_splits(32760, 32760, 6, cpu, ncu=256) == 1
+    assert ops.attention_splits(32760, 32760, 3, cpu, ncu=256) == 2
+    assert ops.attention_splits(32760, 32760, 2, cpu, ncu=256) == 1  # exactly one full round
+    assert ops.attention_splits(32760, 32760, 1, cpu, ncu=256) >= 2
+    assert ops.attention_splits(32760, 512, 12, cpu, ncu=256) == 1

@@ -53,12 +53,14 @@ def set_attention_timer(t):
 _N_CU = {}
 
 
-def attention_splits(Lq, Lk, num_heads, device):
+def attention_splits(Lq, Lk, num_heads, device, ncu=None):
     """Key splits for wanq_attention_fwd_split: > 1 only when (query blocks x heads) leaves much of the last round of CUs idle
     and the key sequence is long enough to share (e.g. 3 heads x 128 blocks on 256 CUs: 1.5 rounds cost 2 -> split 2)."""
-    if device not in _N_CU:
-        _N_CU[device] = torch.cuda.get_device_properties(device).multi_processor_count
-    ncu, blocks, tiles = _N_CU[device], -(-Lq // 256) * num_heads, -(-Lk // 64)
+    if ncu is None:
+        if device not in _N_CU:
+            _N_CU[device] = torch.cuda.get_device_properties(device).multi_processor_count
+        ncu = _N_CU[device]
+    blocks, tiles = -(-Lq // 256) * num_heads, -(-Lk // 64)
     if tiles < 32:
         return 1
     best, cost = 1, float(-(-blocks // ncu))
