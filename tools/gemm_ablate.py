@@ -1,3 +1,4 @@
+"""int8 GEMM at the three cfg-B block shapes: full dequant epilogue (bf16 out) against the raw int32 output."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "wan2.1-quantization_amd"))
@@ -18,4 +19,4 @@ for (M, N, K) in [(32760, 1536, 1536), (32760, 1536, 8960), (32760, 8960, 1536)]
     sw = torch.rand(N, device=dev) * 0.01; zp = torch.randn(N, device=dev); bias = torch.randn(N, device=dev)
     t = timeit(lambda: qgemm.w8a8_linear(a, w, sa, sw, bias, asum, zp, out_dtype=torch.bfloat16))
     t32 = timeit(lambda: qgemm.w8a8_o32(a, w))
-    print(f"DBG={os.environ.get('WANQ_GEMM_DBG','0')} M={M} N={N} K={K}: bf16-epi {t*1e6:8.1f} us {2.0*M*N*K/t/1e12:7.1f} TOPS | o32 {t32*1e6:8.1f} us")
+    print(f"M={M} N={N} K={K}: bf16-epi {t*1e6:8.1f} us {2.0*M*N*K/t/1e12:7.1f} TOPS | o32 {t32*1e6:8.1f} us")
