@@ -246,7 +246,7 @@ def main():
 
     gs = timer.summary()
     out = {
-        "metric": "denoising steps/sec Wan2.1-1.3B W8A8 832x480x81f", "value": args.steps / dt, "unit": "steps/s",
+        "metric": "denoising steps/sec Wan2.1-%s W8A8 %sx%df" % (args.model.split("-")[-1], args.size.replace("*", "x"), args.frames), "value": args.steps / dt, "unit": "steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
         "config": {"workload": f"Wan2.1-{args.model} DiT, {n_quant} Linears W8A8 (W asym per-channel static, A sym per-token dynamic; "
