@@ -8,6 +8,14 @@ from .base import QuantParams
 
 
 class LayerNormGeneral(nn.Module):
+    """Module form of `fused.layernorm_nobias_t2i_quant_sum_fuse`.
+
+    Differences from the CUDA module it stands in for, all of them relaxations: the input may be fp16, bf16 or fp32 (the
+    statistics are fp32 either way), `hidden_size` is not limited to 4096 / 8192 (one wave per row up to 2048 columns, four
+    beyond), the scale / sum buffers of `quant_params` may be fp16 (the reference's layout) or fp32, and a bad argument
+    raises RuntimeError instead of aborting the process.  `act_sum` is kept for signature compatibility: the row sum is
+    written whenever `quant_params.sum_input` exists, which is what every caller in the reference sets up."""
+
     def __init__(self, hidden_size, act_sum=False, eps=1e-6):
         super().__init__()
         self.hidden_size = hidden_size

@@ -9,6 +9,13 @@ from .base import QuantParams
 
 
 class W8A8OF16LinearDynamicInputScale(nn.Module):
+    """Module form of `qgemm.w8a8_of16_bias_weight_asym / _sym` (one int8 MFMA GEMM with the dequantisation in its epilogue).
+
+    Relaxations against the CUDA module: no padding of M to 128 rows or of the scale / sum vectors is needed (any M, N % 8
+    == 0, K % 16 == 0), the GEMM runs on the caller's current stream rather than the legacy default stream, and shape or
+    dtype violations raise RuntimeError instead of tripping a C assert.  The symmetric variant really calls the symmetric
+    epilogue (the reference's forward always takes the asymmetric kernel and needs a zero-point buffer for it)."""
+
     def __init__(self, in_features, out_features, has_bias=True, weight_sym=True):
         super().__init__()
         self.in_features, self.out_features = in_features, out_features
