@@ -289,7 +289,7 @@ def main():
         rng = (yf.max() - yf.min()).item()
         out["quality"] = {"tensor": "DiT output latent (noise_pred)", "rel_l2_vs_fp": ((yq - yf).norm() / yf.norm()).item(),
                           "psnr_db_vs_fp": 10 * torch.log10(torch.tensor(rng * rng / mse)).item()}
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # reported at N = 1 only
         out["cpu_baseline"] = cpu_baseline(cfg, seq_len)
     if rank == 0:
         if rehearse:
