@@ -117,33 +117,41 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
   // chunk c ^ swz(row).
   typedef __attribute__((address_space(3))) void lds_void;
   typedef __attribute__((address_space(1))) const void glb_void;
-  const int d_row0 = 8 * wave + (lane >> 4), d_row1 = d_row0 + 4;
-  const int d_col0 = head * AT_D + (((lane & 15) ^ (((d_row0 & 3) << 2) | ((d_row0 >> 2) & 3))) << 3);
-  const int d_col1 = head * AT_D + (((lane & 15) ^ (((d_row1 & 3) << 2) | ((d_row1 >> 2) & 3))) << 3);
+  // The FIRST-dispatched half of the workgroup (waves 0-3) issues the whole tile, 8 pieces per wave (rows 16w+4i..+3 of the K
+  // tile and of the V tile, i = 0..3): those waves win the issue arbitration against their SIMD partners and would otherwise
+  // wait ~900 cycles per tile at the barrier (phase stamps), and a piece costs less when only four waves issue.
+  const bool dma_wave = wave < 4;
+  const int d_r = lane >> 4;
+#define AT_DOFF(stride, i) ((uint32_t)((16 * (wave & 3) + 4 * (i) + d_r) * (int)(stride) + head * AT_D + ((((lane & 15) ^ (d_r << 2)) ^ (i)) << 3)) * 2u)
   // Per-lane byte offsets inside a tile are constants; a tile's base address is wave-uniform (scalar ALU), so a DMA costs no
   // vector arithmetic: `base + zero-extended 32-bit lane offset` is the instruction's own sgpr + vgpr addressing.  (The
   // 64-bit `row * stride` per lane and instruction it replaces cost ~20 quarter-rate integer multiplies per tile and
-  // wave -- 0.45-0.8 ms of a 6-ms kernel.)  Only a ragged last tile clamps rows, on the slow path.
-  const uint32_t d_kb0 = (uint32_t)(d_row0 * (int)p.k_stride + d_col0) * 2u, d_kb1 = (uint32_t)(d_row1 * (int)p.k_stride + d_col1) * 2u;
-  const uint32_t d_vb0 = (uint32_t)(d_row0 * (int)p.v_stride + d_col0) * 2u, d_vb1 = (uint32_t)(d_row1 * (int)p.v_stride + d_col1) * 2u;
+  // wave.)  Only a ragged last tile clamps rows, on the slow path.
+  const uint32_t d_k0 = AT_DOFF(p.k_stride, 0), d_k1 = AT_DOFF(p.k_stride, 1), d_k2 = AT_DOFF(p.k_stride, 2), d_k3 = AT_DOFF(p.k_stride, 3);
+  const uint32_t d_v0 = AT_DOFF(p.v_stride, 0), d_v1 = AT_DOFF(p.v_stride, 1), d_v2 = AT_DOFF(p.v_stride, 2), d_v3 = AT_DOFF(p.v_stride, 3);
+#undef AT_DOFF
+#define AT_DMA_F(base, off, tilebyte, i) \
+  __builtin_amdgcn_global_load_lds((glb_void*)((base) + (off)), (lds_void*)(sK_ + (tilebyte) + 1024 * (i)), 16, 0, 0);
+#define AT_DMA_S(base, stride, tilebyte, i, j)                                                                   \
+  {                                                                                                             \
+    int kr_ = (j) * AT_KB + 16 * (wave & 3) + 4 * (i) + d_r;                                                    \
+    kr_ = kr_ < p.Lk ? kr_ : p.Lk - 1;                                                                          \
+    const int col_ = head * AT_D + ((((lane & 15) ^ (d_r << 2)) ^ (i)) << 3);                                   \
+    __builtin_amdgcn_global_load_lds((glb_void*)((base) + (int64_t)kr_ * (stride) + col_), (lds_void*)(sK_ + (tilebyte) + 1024 * (i)), 16, 0, 0); \
+  }
 #define AT_DMA(j, stage)                                                                                        \
   do {                                                                                                          \
-    char* sK_ = smem + (stage) * AT_STAGE + wave * 2048;                                                        \
-    if (((j) + 1) * AT_KB <= p.Lk) {                                                                            \
-      const char* kt_ = reinterpret_cast<const char*>(p.k) + (int64_t)(j) * (AT_KB * 2) * p.k_stride;           \
-      const char* vt_ = reinterpret_cast<const char*>(p.v) + (int64_t)(j) * (AT_KB * 2) * p.v_stride;           \
-      __builtin_amdgcn_global_load_lds((glb_void*)(kt_ + d_kb0), (lds_void*)(sK_), 16, 0, 0);                   \
-      __builtin_amdgcn_global_load_lds((glb_void*)(kt_ + d_kb1), (lds_void*)(sK_ + 1024), 16, 0, 0);            \
-      __builtin_amdgcn_global_load_lds((glb_void*)(vt_ + d_vb0), (lds_void*)(sK_ + AT_TILE), 16, 0, 0);         \
-      __builtin_amdgcn_global_load_lds((glb_void*)(vt_ + d_vb1), (lds_void*)(sK_ + AT_TILE + 1024), 16, 0, 0);  \
-    } else {                                                                                                    \
-      int kr0 = (j) * AT_KB + d_row0, kr1 = kr0 + 4;                                                            \
-      kr0 = kr0 < p.Lk ? kr0 : p.Lk - 1;                                                                        \
-      kr1 = kr1 < p.Lk ? kr1 : p.Lk - 1;                                                                        \
-      __builtin_amdgcn_global_load_lds((glb_void*)(p.k + (int64_t)kr0 * p.k_stride + d_col0), (lds_void*)(sK_), 16, 0, 0);                  \
-      __builtin_amdgcn_global_load_lds((glb_void*)(p.k + (int64_t)kr1 * p.k_stride + d_col1), (lds_void*)(sK_ + 1024), 16, 0, 0);           \
-      __builtin_amdgcn_global_load_lds((glb_void*)(p.v + (int64_t)kr0 * p.v_stride + d_col0), (lds_void*)(sK_ + AT_TILE), 16, 0, 0);        \
-      __builtin_amdgcn_global_load_lds((glb_void*)(p.v + (int64_t)kr1 * p.v_stride + d_col1), (lds_void*)(sK_ + AT_TILE + 1024), 16, 0, 0); \
+    if (dma_wave) {                                                                                             \
+      char* sK_ = smem + (stage) * AT_STAGE + (wave & 3) * 4096;                                                \
+      if (((j) + 1) * AT_KB <= p.Lk) {                                                                          \
+        const char* kt_ = reinterpret_cast<const char*>(p.k) + (int64_t)(j) * (AT_KB * 2) * p.k_stride;         \
+        const char* vt_ = reinterpret_cast<const char*>(p.v) + (int64_t)(j) * (AT_KB * 2) * p.v_stride;         \
+        AT_DMA_F(kt_, d_k0, 0, 0) AT_DMA_F(kt_, d_k1, 0, 1) AT_DMA_F(kt_, d_k2, 0, 2) AT_DMA_F(kt_, d_k3, 0, 3)  \
+        AT_DMA_F(vt_, d_v0, AT_TILE, 0) AT_DMA_F(vt_, d_v1, AT_TILE, 1) AT_DMA_F(vt_, d_v2, AT_TILE, 2) AT_DMA_F(vt_, d_v3, AT_TILE, 3) \
+      } else {                                                                                                  \
+        AT_DMA_S(p.k, p.k_stride, 0, 0, j) AT_DMA_S(p.k, p.k_stride, 0, 1, j) AT_DMA_S(p.k, p.k_stride, 0, 2, j) AT_DMA_S(p.k, p.k_stride, 0, 3, j) \
+        AT_DMA_S(p.v, p.v_stride, AT_TILE, 0, j) AT_DMA_S(p.v, p.v_stride, AT_TILE, 1, j) AT_DMA_S(p.v, p.v_stride, AT_TILE, 2, j) AT_DMA_S(p.v, p.v_stride, AT_TILE, 3, j) \
+      }                                                                                                         \
     }                                                                                                           \
   } while (0)
 
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     AT_DMA(jt0, 0);
     if (jt0 + 1 < jt1) {
       AT_DMA(jt0 + 1, 1);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -337,8 +345,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     }
     STAMP(3)
     if (DMA) {
-      // tile j+1 must have landed; the four instructions of tile j+2 (if issued) may stay in flight
-      if (j + 2 < jt1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      // tile j+1 must have landed; the eight instructions of tile j+2 (if issued; waves 4-7 issue none) may stay in flight
+      if (j + 2 < jt1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       st3 = st3 == 2 ? 0 : st3 + 1;
       STAMP(4)
