@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Bitwise run-to-run determinism of every HIP entry point the block uses (no atomics anywhere, so any difference is a race):
+each case is launched REPS times on the same inputs and compared with its first result."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "wan2.1-quantization_amd"))
+import viditq_extension.fused as fused  # noqa: E402
+import viditq_extension.qgemm as qgemm  # noqa: E402
+from qdiff.quarot import quarot_utils as qu  # noqa: E402
+from wan import ops  # noqa: E402
+
+DEV, REPS = "cuda", int(os.environ.get("REPS", 60))
+g = torch.Generator(device=DEV).manual_seed(0)
+
+
+def check(name, fn):
+    first = fn()
+    first = [t.clone() for t in (first if isinstance(first, (list, tuple)) else [first])]
+    bad = 0
+    for _ in range(REPS):
+        out = fn()
+        out = out if isinstance(out, (list, tuple)) else [out]
+        bad += any(not torch.equal(a, b) for a, b in zip(first, out))
+    print(f"{name:55s} {'DETERMINISTIC' if bad == 0 else f'{bad}/{REPS} runs differ'}", flush=True)
+
+
+for (Lq, Lk, H, kl) in [(270, 270, 4, None), (270, 24, 4, None), (1000, 1000, 2, 937), (4680, 4680, 12, None), (300, 5000, 1, None)]:
+    q = torch.randn(Lq, H * 128, device=DEV, generator=g).to(torch.bfloat16)
+    k = torch.randn(Lk, H * 128, device=DEV, generator=g).to(torch.bfloat16)
+    v = torch.randn(Lk, H * 128, device=DEV, generator=g).to(torch.bfloat16)
+    check(f"attention Lq={Lq} Lk={Lk} H={H} klen={kl}", lambda: ops.attention(q, k, v, H, kl, splits=1))
+    check(f"attention Lq={Lq} Lk={Lk} H={H} klen={kl} splits=2", lambda: ops.attention(q, k, v, H, kl, splits=2))
+
+for (M, N, K) in [(270, 512, 512), (270, 1024, 512), (24, 512, 512), (4680, 1536, 1536), (4680, 8960, 1536), (4680, 1536, 8960)]:
+    a = torch.randint(-128, 128, (M, K), dtype=torch.int8, device=DEV, generator=g)
+    w = torch.randint(-128, 128, (N, K), dtype=torch.int8, device=DEV, generator=g)
+    sa, asum = torch.rand(M, device=DEV, generator=g) * 0.01, torch.rand(M, device=DEV, generator=g)
+    sw, zp, bias = torch.rand(N, device=DEV, generator=g) * 0.01, torch.randn(N, device=DEV, generator=g), torch.randn(N, device=DEV, generator=g)
+    gate, res = torch.randn(N, device=DEV, generator=g), torch.randn(M, N, device=DEV, generator=g)
+    check(f"gemm {M}x{N}x{K} bf16", lambda: qgemm.w8a8_linear(a, w, sa, sw, bias, asum, zp, out_dtype=torch.bfloat16))
+    check(f"gemm {M}x{N}x{K} bf16 gelu", lambda: qgemm.w8a8_linear(a, w, sa, sw, bias, asum, zp, out_dtype=torch.bfloat16, gelu=True))
+    check(f"gemm {M}x{N}x{K} fp32 gate+res", lambda: qgemm.w8a8_linear(a, w, sa, sw, bias, asum, zp, out_dtype=torch.float32, gate=gate, residual=res,
+                                                                    out=torch.empty_like(res)))
+
+for (rows, C) in [(270, 512), (270, 1536), (4680, 1536), (270, 5120)]:
+    x = torch.randn(rows, C, device=DEV, generator=g)
+    sh, sc = torch.randn(1, C, device=DEV, generator=g) * 0.1, torch.randn(1, C, device=DEV, generator=g) * 0.1
+    pms = [torch.randn(C, device=DEV, generator=g) for _ in range(3)]
+    rot = qu.kernel_rotation_params(C, DEV)
+
+    def multi():
+        qs = [torch.empty(rows, C, dtype=torch.int8, device=DEV) for _ in range(3)]
+        sc_, su_ = [torch.zeros(rows, device=DEV) for _ in range(3)], [torch.zeros(rows, device=DEV) for _ in range(3)]
+        fused.layernorm_rotate_quant_multi(qs, x, None, sh, sc, pms, rot, su_, sc_, 1e-6)
+        return qs + sc_ + su_
+
+    def single():
+        q_ = torch.empty(rows, C, dtype=torch.int8, device=DEV)
+        s_, u_ = torch.zeros(rows, device=DEV), torch.zeros(rows, device=DEV)
+        fused.layernorm_rotate_quant(q_, x, None, sh, sc, pms[0], rot, u_, s_, 1e-6)
+        return [q_, s_, u_]
+
+    def plain():
+        q_ = torch.empty(rows, C, dtype=torch.int8, device=DEV)
+        s_, u_ = torch.zeros(rows, device=DEV), torch.zeros(rows, device=DEV)
+        fused.layernorm_nobias_t2i_quant_sum_fuse(q_, x, None, sh, sc, u_, s_, 1e-6)
+        return [q_, s_, u_]
+
+    check(f"LN+rotate+quant x3 [{rows},{C}]", multi)
+    check(f"LN+rotate+quant    [{rows},{C}]", single)
+    check(f"LN+quant           [{rows},{C}]", plain)
+    xb = x.to(torch.bfloat16)
+    check(f"quant bf16         [{rows},{C}]", lambda: [fused.quant_sum(xb, torch.zeros(rows, device=DEV), torch.zeros(rows, device=DEV))])
+
+for (rows, H) in [(270, 4), (4680, 12)]:
+    x = torch.randn(rows, H * 128, device=DEV, generator=g).to(torch.bfloat16)
+    w = torch.rand(H * 128, device=DEV, generator=g) + 0.5
+    rope = torch.randn(rows, 64, 2, device=DEV, generator=g)
+    check(f"rmsnorm_rope       [{rows},{H*128}]", lambda: ops.rmsnorm_rope_(x.clone(), w, rope, 128, eps=1e-6))

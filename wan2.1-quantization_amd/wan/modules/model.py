@@ -166,12 +166,23 @@ class WanModel(nn.Module):
                                 rope_params(1024, 2 * (d // 6))], dim=1)
         self.init_weights()
 
+    def _patch_embed(self, u):
+        """patch_embedding(u) for kernel == stride (model.py:580-582 of the reference calls the Conv3d): the convolution is a
+        Linear over non-overlapping patches, evaluated as such -- one GEMM instead of MIOpen's solver search, which on this
+        stack lands on a 3-ms naive kernel per call and may pick different solvers in different processes (the two-rank
+        rehearsal caught ranks disagreeing at 5e-4).  u [C, F, H, W] -> ([L, dim] tokens in (f, h, w) order, grid)."""
+        c, f, h, w = u.shape
+        pt, ph, pw = self.patch_size
+        grid = (f // pt, h // ph, w // pw)
+        patches = u.view(c, grid[0], pt, grid[1], ph, grid[2], pw).permute(1, 3, 5, 0, 2, 4, 6).reshape(grid[0] * grid[1] * grid[2], -1)
+        return torch.nn.functional.linear(patches, self.patch_embedding.weight.flatten(1), self.patch_embedding.bias), grid
+
     # ---- pieces shared with the kernel-mode model (wan/quant_wanx_hip.py)
     def embed(self, x, t, context, seq_len):
         dev = self.patch_embedding.weight.device
-        x = [self.patch_embedding(u.unsqueeze(0).to(self.patch_embedding.weight.dtype)) for u in x]
-        grid_sizes = [tuple(u.shape[2:]) for u in x]
-        x = [u.flatten(2).transpose(1, 2) for u in x]
+        x = [self._patch_embed(u.to(self.patch_embedding.weight.dtype)) for u in x]
+        grid_sizes = [g for _, g in x]
+        x = [u.unsqueeze(0) for u, _ in x]
         seq_lens = [u.size(1) for u in x]
         assert max(seq_lens) <= seq_len
         x = torch.cat([torch.cat([u, u.new_zeros(1, seq_len - u.size(1), u.size(2))], dim=1) for u in x])
