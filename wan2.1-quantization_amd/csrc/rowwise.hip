@@ -100,24 +100,16 @@ struct RowReduce {
 // Hadamard rotation (H_K (x) H_128) / sqrt(n) of a row held in registers.  With 8-element chunks, element e =
 // 8*chunk + j has block index k = chunk >> 4 and in-block index r = 8*(chunk & 15) + j, and chunk & 15 == lane & 15:
 // the 128-point Walsh-Hadamard transform is 3 in-register stages (bits of j) + 4 cross-lane stages (lane bits 0..3, inside
-// a DPP row of 16 lanes); the K x K mixing goes through LDS ([k][128] fp32, conflict-free b128 reads).
-// Both halves are arranged to stay off the LDS pipe, which four SIMDs share (the first version spent 200 LDS
-// instructions per wave and row here -- 4 ds_swizzle per value, every input block re-read once per OUTPUT chunk -- and the
-// transform cost as much as the whole LayerNorm+quantise pass around it):
-//  * lane exchanges are DPP moves (VALU): xor 1 / xor 2 = quad_perm, xor 4 = row_half_mirror o quad_perm[3,2,1,0]
-//    (7 ^ 3), xor 8 = row_mirror o row_half_mirror (15 ^ 7);
-//  * all of a lane's chunks sit at the same position c inside their 128-blocks (chunk strides are multiples of 16), so
-//    one pass over the K input blocks feeds every output chunk of the lane.
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
+// a group of 16 lanes: ds_swizzle bit mode, no address VGPR); the K x K mixing goes through LDS ([k][128] fp32, conflict-free
+// b128 reads).  All of a lane's chunks sit at the same position c inside their 128-blocks (chunk strides are multiples of
+// 16), so ONE pass over the K input blocks feeds every output chunk of the lane (the first version re-read every input block
+// once per output chunk).  A DPP form of the lane exchanges (quad_perm / row_half_mirror / row_mirror compositions) measured
+// the same time and is not used: in a two-process stress (two full models sharing one GPU, i.e. with wave preemption) the
+// transform kernels showed rare single-row deviations in both forms, 2-3x more often with DPP; alone, or beside a second
+// process running only these kernels, both forms are bit-reproducible (tools/determinism_check.py).
 template <int BIT>
 __device__ __forceinline__ float lane_xor16(float v) {
-  if (BIT == 1) return dpp_mov<0xB1>(v);                  // quad_perm [1,0,3,2]
-  if (BIT == 2) return dpp_mov<0x4E>(v);                  // quad_perm [2,3,0,1]
-  if (BIT == 4) return dpp_mov<0x1B>(dpp_mov<0x141>(v));  // row_half_mirror, then quad_perm [3,2,1,0]
-  return dpp_mov<0x141>(dpp_mov<0x140>(v));               // row_mirror, then row_half_mirror
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (BIT << 10) | 0x1f));  // and 0x1f, or 0, xor BIT
 }
 template <int BIT, int NCH>
 __device__ __forceinline__ void butterfly_lanes(float (&v)[NCH][8], int lane) {
