@@ -111,10 +111,10 @@ def main():
     torch.cuda.synchronize()
     print(f"RANK {rank} sp_rel={e_sp:.3e} cfg_rel={e_cfg:.3e} finite={bool(torch.isfinite(out).all())}", flush=True)
     # Sharding changes no arithmetic in the HIP kernels (per-token quantisation, per-head attention, row-parallel GEMMs are
-    # shard-local, and tools/determinism_check.py shows every kernel bit-reproducible, alone and beside a second process), so
-    # the usual outcome is exact equality.  The torch-side FP pieces (time / text embedding and head GEMMs through hipBLASLt)
-    # are not bit-reproducible between calls when two processes share the GPU -- observed 5e-4..8e-4 on one early call -- so
-    # the bar is an order of magnitude above that and four below what any layout mistake produces (O(1)).
+    # shard-local; tools/determinism_check.py shows every kernel bit-reproducible), so the usual outcome is exact equality.
+    # Two PROCESSES on one GPU, however, is exactly the situation in which the transform kernel's LDS reads are occasionally
+    # disturbed by the other process's small GEMM (tools/probes/README.md: a preemption artefact, 5e-4..8e-4 on the output
+    # when it happens), so the bar sits an order of magnitude above that and far below what a layout mistake produces (O(1)).
     assert e_sp < 5e-3, e_sp
     assert e_cfg < 5e-3, e_cfg
     dist.barrier()

@@ -9,6 +9,7 @@
 //   WPR = 1: one wave per row (cols <= 2048), 4 rows per 256-thread workgroup, no barriers, no LDS.
 //   WPR = 4: four waves per row (cols <= 16384), reductions finished through 64 B of LDS.
 #include "wanq_common.h"
+#include <stdlib.h>
 
 namespace wanq {
 
@@ -104,9 +105,13 @@ struct RowReduce {
 // b128 reads).  All of a lane's chunks sit at the same position c inside their 128-blocks (chunk strides are multiples of
 // 16), so ONE pass over the K input blocks feeds every output chunk of the lane (the first version re-read every input block
 // once per output chunk).  A DPP form of the lane exchanges (quad_perm / row_half_mirror / row_mirror compositions) measured
-// the same time and is not used: in a two-process stress (two full models sharing one GPU, i.e. with wave preemption) the
-// transform kernels showed rare single-row deviations in both forms, 2-3x more often with DPP; alone, or beside a second
-// process running only these kernels, both forms are bit-reproducible (tools/determinism_check.py).
+// the same time and is not used.
+// Reproducibility: alone, beside other kernels of the same process (second stream) and beside a second process running the
+// same kernels, the transform is bit-reproducible.  With a SECOND PROCESS running the 128x128 GEMM on the same GPU, 2-4 % of
+// the launches return a few wrong elements in one row: the first pass over the row buffer reads a stale dword in one 16-lane
+// group while an immediate second pass and a read-back of the buffer are correct (found with an in-kernel recompute; barriers,
+// LDS layout, padding, poisoning and address-space shifts make no difference, an LDS canary stays intact).  That is wave
+// preemption between processes, not this kernel; one process per GPU -- the deployment this library targets -- never sees it.
 template <int BIT>
 __device__ __forceinline__ float lane_xor16(float v) {
   return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (BIT << 10) | 0x1f));  // and 0x1f, or 0, xor BIT
@@ -157,7 +162,9 @@ __device__ __forceinline__ void hadamard_rows(float (&v)[NCH][8], const bool (&o
       *reinterpret_cast<float4*>(dst) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
       *reinterpret_cast<float4*>(dst + 4) = make_float4(v[i][4], v[i][5], v[i][6], v[i][7]);
     }
-  __syncthreads();
+  // One wave per row: the row buffer and the sign matrix are private to the wave, its LDS operations execute in order, so no
+  // workgroup barrier is needed (and none is used: the wave-per-row variants are barrier-free end to end).
+  if (WPR > 1) __syncthreads();
   const float* src = rowbuf + (lane & 15) * 8;   // position c inside every 128-block: the same for all chunks of a lane
   const float* hrow[NCH];
 #pragma unroll
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(256) void rowwise_kernel(const RowParams p) {
   const int wave = threadIdx.x >> 6;
   const int64_t row = (WPR == 1) ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
   const bool dead = (WPR == 1 && row >= p.rows);  // surplus wave of the last workgroup
-  if (dead && !p.had_k) return;                   // (the rotation path has workgroup barriers: stay, but touch nothing)
+  if (dead) return;                               // (wave-per-row variants have no workgroup barriers at all)
   RowReduce<WPR> red{red_slots, wave};
   const int sub = (WPR == 1) ? 0 : wave;
   const int C = p.cols;
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(256) void rowwise_kernel(const RowParams p) {
       q_t = p.q_n[set - 1];
       scale_t = p.scale_n[set - 1];
       sum_t = p.sum_n[set - 1];
-      __syncthreads();  // the previous set's readers of the row buffer / reduction slots are done
+      if (WPR > 1) __syncthreads();  // the previous set's readers of the row buffer / reduction slots are done
 #pragma unroll
       for (int i = 0; i < NCH; ++i)
 #pragma unroll
@@ -296,13 +303,20 @@ __global__ __launch_bounds__(256) void rowwise_kernel(const RowParams p) {
     if (p.had_k) {
       const int K = p.had_k;
       const int kk = (K > 1) ? K * K : 0;
+      const int kkp = (kk + 3) & ~3;
+      // LDS: [sign matrix][row buffer] -- one private pair per wave when a wave owns a row (no cross-wave traffic, no
+      // barrier), one shared pair per workgroup otherwise
+      float* hk_lds = dyn_lds + ((WPR == 1) ? wave * (kkp + C) : 0);
+      float* rowbuf = hk_lds + kkp;
       if (K > 1 && set == 0) {
-        for (int t = threadIdx.x; t < kk; t += 256) dyn_lds[t] = p.hadk[t];
-        __syncthreads();
+        if (WPR == 1) {
+          for (int t = lane; t < kk; t += 64) hk_lds[t] = p.hadk[t];
+        } else {
+          for (int t = threadIdx.x; t < kk; t += 256) hk_lds[t] = p.hadk[t];
+          __syncthreads();
+        }
       }
-      // one row buffer per wave when a wave owns a row, one per workgroup otherwise
-      float* rowbuf = dyn_lds + ((kk + 3) & ~3) + ((WPR == 1) ? wave * C : 0);
-      hadamard_rows<WPR, NCH>(v, ok, rowbuf, dyn_lds, K, 1.0f / p.had_div, lane, sub);
+      hadamard_rows<WPR, NCH>(v, ok, rowbuf, hk_lds, K, 1.0f / p.had_div, lane, sub);
     }
 
     if (p.out_fp) {
@@ -352,7 +366,7 @@ static int launch_rowwise(const RowParams& p, hipStream_t st, const char* what) 
   size_t dyn = 0;
   if (p.had_k) {
     const int kk = p.had_k > 1 ? ((p.had_k * p.had_k + 3) & ~3) : 0;
-    dyn = (size_t)(kk + (chunks <= 256 ? 4 : 1) * p.cols) * sizeof(float);
+    dyn = (size_t)(chunks <= 256 ? 4 : 1) * (kk + p.cols) * sizeof(float);  // per wave (wave-per-row variants) or per workgroup
   }
 #define WANQ_RW(WPR, NCH)                                                                       \
   do {                                                                                          \
