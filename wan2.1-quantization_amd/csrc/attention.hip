@@ -239,6 +239,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     }
     STAMP(1)
     if (j == nt - 1 && (p.Lk & (AT_KB - 1))) {  // ragged last tile: keys >= Lk get -inf
+      asm volatile("" ::: "memory");  // keeps this a branch: if-converted, it costs 32 selects per lane on EVERY tile
       const int kb = j * AT_KB + 4 * fh;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
