@@ -153,31 +153,33 @@ int wanq_attention_fwd_split(const void* q, const void* k, const void* v, void* 
 /* ------------------------------------------------------------------------------------------------
  * ViDiT activation transform fused with the per-token quantiser:
  *   y = hadU(x * premul),   hadU = (H_K (x) H_128) / sqrt(cols)   (natural-order Walsh-Hadamard on each
- *   128-wide block, then the +-1 matrix hadk[K,K] across blocks)
- * premul fp32[cols] = channel_mask * rotation_signs (either may be all ones), or NULL; had_k = 0 disables the
- * rotation, otherwise cols must equal had_k * 128 (1536 -> 12, 5120 -> 40, 2^p -> 2^p/128 with a Sylvester hadk).
+ *   128-wide block, then the reference's +-1 table of order K across blocks)
+ * premul fp32[cols] = channel_mask * rotation_signs (either may be all ones), or NULL.  had_k must equal cols / 128
+ * (the caller states the factorisation it expects); the table across blocks is the one get_hadK picks for this width
+ * (ViDiT-Q/quant_utils/qdiff/quarot/quarot_utils.py:100-155), a fixed function of cols: Sylvester for 2^p (had_k <= 32),
+ * Paley-I of order 12 for 1536, H_2 (x) Paley-I of order 20 for 5120 -- generated inside the library, not passed in.
  * Equals `x*channel_mask -> (x.double() @ rotation_matrix)` of ViDiTQuantizedLinear.forward
  * (ViDiT-Q/quant_utils/qdiff/viditq/viditq_quant_layer.py:62-63) because row i of the random Hadamard
- * matrix is sign_i * hadU(e_i) (quarot_utils.py:186-192); evaluated in fp32 with O(n log n + nK) adds instead
- * of a dense fp64 GEMM.  Outputs: fp (out_fp) and/or int8 codes + scale (+sum), as wanq_quant_rows. */
-int wanq_rotate_quant_rows(const void* x, int x_dtype, const float* premul, const float* hadk, int had_k,
-                           void* out_fp, int out_dtype, int8_t* q, void* scale, void* sum, int vec_dtype,
-                           int64_t rows, int cols, int act, void* stream);
+ * matrix is sign_i * hadU(e_i) (quarot_utils.py:186-192); evaluated in fp32 registers with O(n log n + nK) adds instead
+ * of a dense fp64 GEMM, no LDS.  Outputs: fp (out_fp) and/or int8 codes + scale (+sum), as wanq_quant_rows.  (No activation
+ * option: tanh-GELU in front of a transformed layer is fused into the producing GEMM, WANQ_EPI_GELU.) */
+int wanq_rotate_quant_rows(const void* x, int x_dtype, const float* premul, int had_k, void* out_fp, int out_dtype,
+                           int8_t* q, void* scale, void* sum, int vec_dtype, int64_t rows, int cols, void* stream);
 
 /* LayerNorm -> modulate (as wanq_layernorm_rows) -> ViDiT transform -> int8 quantise, one kernel. */
 int wanq_layernorm_rotate_quant_rows(const void* x, int x_dtype, const void* gamma, const void* mshift,
                                      const void* mscale, int mod_dtype, int64_t mod_stride, int64_t rows_per_batch,
-                                     float eps, const float* premul, const float* hadk, int had_k, int8_t* q,
-                                     void* scale, void* sum, int vec_dtype, int64_t rows, int cols, void* stream);
+                                     float eps, const float* premul, int had_k, int8_t* q, void* scale, void* sum,
+                                     int vec_dtype, int64_t rows, int cols, void* stream);
 
 /* The same, for up to three consumers of ONE normalised row: self-attention q / k / v share norm1 and the modulation
  * (ViDiT-Q/examples/Wan2.1/wan/modules/model.py:327-331) but each ViDiTQuantizedLinear has its own channel mask and
  * rotation signs (viditq_quant_layer.py:30-38), so the reference normalises, scales, rotates (fp64 GEMM) and quantises
  * three times.  Here x is read and normalised once; set t gets hadU(LN(x) * premul[t]) quantised into q[t] / scale[t] /
- * sum[t].  premul / q / scale / sum are host arrays of nsets (1..3) device pointers; hadk / had_k are shared. */
+ * sum[t].  premul / q / scale / sum are host arrays of nsets (1..3) device pointers. */
 int wanq_layernorm_rotate_quant_rows_multi(const void* x, int x_dtype, const void* gamma, const void* mshift,
                                            const void* mscale, int mod_dtype, int64_t mod_stride, int64_t rows_per_batch,
-                                           float eps, int nsets, const float* const* premul, const float* hadk, int had_k,
+                                           float eps, int nsets, const float* const* premul, int had_k,
                                            int8_t* const* q, void* const* scale, void* const* sum, int vec_dtype,
                                            int64_t rows, int cols, void* stream);
 

@@ -35,18 +35,6 @@ struct RowParams {
   int cols;
   int act;
   int static_amax;
-  // ViDiT transform before quantisation (Q/viditq/viditq_quant_layer.py:62-63): y = hadU(x * premul)
-  const float* premul;  // [cols] channel_mask * rotation signs, or NULL
-  const float* hadk;    // [K, K] +-1 matrix (row-major) or NULL when K == 1
-  int had_k;            // 0 = no rotation; else cols == had_k * 128
-  float had_div;        // fp32 sqrt(cols): the reference divides by torch.tensor(n).sqrt()
-  // further (premul, q, scale, sum) sets computed from the SAME normalised row (q / k / v of one block share LayerNorm and
-  // modulation but have their own channel mask and rotation signs): nsets in 1..3, set 0 = the fields above
-  int nsets;
-  const float* premul_n[2];
-  int8_t* q_n[2];
-  void* scale_n[2];
-  void* sum_n[2];
 };
 
 __device__ __forceinline__ void load8_rt(const void* base, int dt, int64_t elem, float (&v)[8]) {
@@ -98,110 +86,13 @@ struct RowReduce {
   }
 };
 
-// Hadamard rotation (H_K (x) H_128) / sqrt(n) of a row held in registers.  With 8-element chunks, element e =
-// 8*chunk + j has block index k = chunk >> 4 and in-block index r = 8*(chunk & 15) + j, and chunk & 15 == lane & 15:
-// the 128-point Walsh-Hadamard transform is 3 in-register stages (bits of j) + 4 cross-lane stages (lane bits 0..3, inside
-// a group of 16 lanes: ds_swizzle bit mode, no address VGPR); the K x K mixing goes through LDS ([k][128] fp32, conflict-free
-// b128 reads).  All of a lane's chunks sit at the same position c inside their 128-blocks (chunk strides are multiples of
-// 16), so ONE pass over the K input blocks feeds every output chunk of the lane (the first version re-read every input block
-// once per output chunk).  A DPP form of the lane exchanges (quad_perm / row_half_mirror / row_mirror compositions) measured
-// the same time and is not used.
-// Reproducibility: alone, beside other kernels of the same process (second stream) and beside a second process running the
-// same kernels, the transform is bit-reproducible.  With a SECOND PROCESS running the 128x128 GEMM on the same GPU, 2-4 % of
-// the launches return a few wrong elements in one row: the first pass over the row buffer reads a stale dword in one 16-lane
-// group while an immediate second pass and a read-back of the buffer are correct (found with an in-kernel recompute; barriers,
-// LDS layout, padding, poisoning and address-space shifts make no difference, an LDS canary stays intact).  That is wave
-// preemption between processes, not this kernel; one process per GPU -- the deployment this library targets -- never sees it.
-template <int BIT>
-__device__ __forceinline__ float lane_xor16(float v) {
-  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (BIT << 10) | 0x1f));  // and 0x1f, or 0, xor BIT
-}
-template <int BIT, int NCH>
-__device__ __forceinline__ void butterfly_lanes(float (&v)[NCH][8], int lane) {
-  const bool up = (lane & BIT) != 0;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float o = lane_xor16<BIT>(v[i][j]);
-      v[i][j] = up ? o - v[i][j] : v[i][j] + o;
-    }
-}
-
-template <int WPR, int NCH>
-__device__ __forceinline__ void hadamard_rows(float (&v)[NCH][8], const bool (&ok)[NCH], float* rowbuf, const float* hk_lds,
-                                              int K, float inv_div, int lane, int sub) {
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-#pragma unroll
-    for (int h = 1; h < 8; h <<= 1)
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (!(j & h)) {
-          const float a = v[i][j], b = v[i][j | h];
-          v[i][j] = a + b;
-          v[i][j | h] = a - b;
-        }
-  }
-  butterfly_lanes<1, NCH>(v, lane);
-  butterfly_lanes<2, NCH>(v, lane);
-  butterfly_lanes<4, NCH>(v, lane);
-  butterfly_lanes<8, NCH>(v, lane);
-  if (K == 1) {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[i][j] *= inv_div;
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < NCH; ++i)
-    if (ok[i]) {
-      const int chunk = sub * 64 + lane + i * 64 * WPR;
-      float* dst = rowbuf + (chunk >> 4) * 128 + (chunk & 15) * 8;
-      *reinterpret_cast<float4*>(dst) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
-      *reinterpret_cast<float4*>(dst + 4) = make_float4(v[i][4], v[i][5], v[i][6], v[i][7]);
-    }
-  // One wave per row: the row buffer and the sign matrix are private to the wave, its LDS operations execute in order, so no
-  // workgroup barrier is needed (and none is used: the wave-per-row variants are barrier-free end to end).
-  if (WPR > 1) __syncthreads();
-  const float* src = rowbuf + (lane & 15) * 8;   // position c inside every 128-block: the same for all chunks of a lane
-  const float* hrow[NCH];
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int chunk = sub * 64 + lane + i * 64 * WPR;
-    hrow[i] = hk_lds + (ok[i] ? (chunk >> 4) : 0) * K;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
-  }
-#pragma unroll 4
-  for (int k2 = 0; k2 < K; ++k2) {
-    const float4 a = *reinterpret_cast<const float4*>(src + k2 * 128);
-    const float4 b = *reinterpret_cast<const float4*>(src + k2 * 128 + 4);
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const float sgn = hrow[i][k2];
-      v[i][0] += sgn * a.x; v[i][1] += sgn * a.y; v[i][2] += sgn * a.z; v[i][3] += sgn * a.w;
-      v[i][4] += sgn * b.x; v[i][5] += sgn * b.y; v[i][6] += sgn * b.z; v[i][7] += sgn * b.w;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const float f = ok[i] ? inv_div : 0.f;  // chunks past the row end stay zero: they take part in the row max and sum
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[i][j] *= f;
-  }
-}
-
-template <int WPR, int NCH, bool LN, bool MULTI = false>
+template <int WPR, int NCH, bool LN>
 __global__ __launch_bounds__(256) void rowwise_kernel(const RowParams p) {
   __shared__ float red_slots[4 * 4];
-  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];  // rotation only: hadK [K*K] then row buffers
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int64_t row = (WPR == 1) ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
-  const bool dead = (WPR == 1 && row >= p.rows);  // surplus wave of the last workgroup
-  if (dead) return;                               // (wave-per-row variants have no workgroup barriers at all)
+  if (WPR == 1 && row >= p.rows) return;  // surplus wave of the last workgroup (wave-per-row variants have no barriers)
   RowReduce<WPR> red{red_slots, wave};
   const int sub = (WPR == 1) ? 0 : wave;
   const int C = p.cols;
@@ -212,7 +103,7 @@ __global__ __launch_bounds__(256) void rowwise_kernel(const RowParams p) {
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c0 = (sub * 64 + lane + i * 64 * WPR) * 8;
-    ok[i] = c0 < C && !dead;
+    ok[i] = c0 < C;
     if (ok[i]) {
       load8_rt(p.x, p.x_dtype, rbase + c0, v[i]);
     } else {
@@ -265,118 +156,50 @@ __global__ __launch_bounds__(256) void rowwise_kernel(const RowParams p) {
       for (int j = 0; j < 8; ++j) v[i][j] = gelu_tanh_f32(v[i][j]);
   }
 
-  // ---- (ViDiT transform,) quantise, store: once, or once per (premul, q, scale, sum) set from the same normalised row
-  const int nsets = MULTI ? p.nsets : 1;
-  float base[MULTI ? NCH : 1][8];
-  if (MULTI) {
+  if (p.out_fp) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (ok[i]) store8_rt(p.out_fp, p.out_dtype, rbase + (sub * 64 + lane + i * 64 * WPR) * 8, v[i]);
+  }
+  if (!p.q) return;
+
+  float amax;
+  if (p.static_amax) {
+    amax = vec_load(p.scale, p.vec_dtype, row);
+  } else {
+    float m = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) base[i][j] = v[i][j];
+      for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[i][j]));
+    amax = red.max(m, 2);
   }
-  for (int set = 0; set < nsets; ++set) {
-    const float* premul_t = p.premul;
-    int8_t* q_t = p.q;
-    void* scale_t = p.scale;
-    void* sum_t = p.sum;
-    if (MULTI && set > 0) {
-      premul_t = p.premul_n[set - 1];
-      q_t = p.q_n[set - 1];
-      scale_t = p.scale_n[set - 1];
-      sum_t = p.sum_n[set - 1];
-      if (WPR > 1) __syncthreads();  // the previous set's readers of the row buffer / reduction slots are done
+  float scale = amax / 127.0f;
+  if (scale < 1e-6f) scale = 1e-6f;  // qdiff eps rule (base_quantizer.py:122-127)
+  const float inv = 1.0f / scale;
+  int isum = 0;
 #pragma unroll
-      for (int i = 0; i < NCH; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[i][j] = base[i][j];
-    }
-    if (premul_t) {
-  #pragma unroll
-      for (int i = 0; i < NCH; ++i)
-        if (ok[i]) {
-          float pm[8];
-          Io<F32>::load8(premul_t, (sub * 64 + lane + i * 64 * WPR) * 8, pm);
-  #pragma unroll
-          for (int j = 0; j < 8; ++j) v[i][j] *= pm[j];
-        }
-    }
-    if (p.had_k) {
-      const int K = p.had_k;
-      const int kk = (K > 1) ? K * K : 0;
-      const int kkp = (kk + 3) & ~3;
-      // LDS: [sign matrix][row buffer] -- one private pair per wave when a wave owns a row (no cross-wave traffic, no
-      // barrier), one shared pair per workgroup otherwise
-      float* hk_lds = dyn_lds + ((WPR == 1) ? wave * (kkp + C) : 0);
-      float* rowbuf = hk_lds + kkp;
-      if (K > 1 && set == 0) {
-        if (WPR == 1) {
-          for (int t = lane; t < kk; t += 64) hk_lds[t] = p.hadk[t];
-        } else {
-          for (int t = threadIdx.x; t < kk; t += 256) hk_lds[t] = p.hadk[t];
-          __syncthreads();
-        }
-      }
-      hadamard_rows<WPR, NCH>(v, ok, rowbuf, hk_lds, K, 1.0f / p.had_div, lane, sub);
-    }
-
-    if (p.out_fp) {
-  #pragma unroll
-      for (int i = 0; i < NCH; ++i)
-        if (ok[i]) store8_rt(p.out_fp, p.out_dtype, rbase + (sub * 64 + lane + i * 64 * WPR) * 8, v[i]);
-    }
-    if (!q_t) return;
-
-    float amax;
-    if (p.static_amax) {
-      amax = dead ? 1.f : vec_load(scale_t, p.vec_dtype, row);
-    } else {
-      float m = 0.f;
-  #pragma unroll
-      for (int i = 0; i < NCH; ++i)
-  #pragma unroll
-        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[i][j]));
-      amax = red.max(m, 2);
-    }
-    float scale = amax / 127.0f;
-    if (scale < 1e-6f) scale = 1e-6f;  // qdiff eps rule (base_quantizer.py:122-127)
-    const float inv = 1.0f / scale;
-    int isum = 0;
-  #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      int qi[8];
-      quant8_div_rne(v[i], scale, inv, qi);
-      const uint32_t lo = pack4_i8_fast(qi[0], qi[1], qi[2], qi[3]), hi = pack4_i8_fast(qi[4], qi[5], qi[6], qi[7]);
-      isum = __builtin_amdgcn_sdot4((int)lo, 0x01010101, isum, false);  // sum of the four signed bytes
-      isum = __builtin_amdgcn_sdot4((int)hi, 0x01010101, isum, false);
-      if (ok[i]) *reinterpret_cast<uint2*>(q_t + rbase + (sub * 64 + lane + i * 64 * WPR) * 8) = make_uint2(lo, hi);
-    }
-    if (sum_t) {
-      const int tot = red.isum(isum, 3);
-      if (lane == 0 && sub == 0 && !dead) vec_store(sum_t, p.vec_dtype, row, (float)tot * scale);
-    }
-    if (!p.static_amax && lane == 0 && sub == 0 && !dead) vec_store(scale_t, p.vec_dtype, row, scale);
-
+  for (int i = 0; i < NCH; ++i) {
+    int qi[8];
+    quant8_div_rne(v[i], scale, inv, qi);
+    const uint32_t lo = pack4_i8_fast(qi[0], qi[1], qi[2], qi[3]), hi = pack4_i8_fast(qi[4], qi[5], qi[6], qi[7]);
+    isum = __builtin_amdgcn_sdot4((int)lo, 0x01010101, isum, false);  // sum of the four signed bytes
+    isum = __builtin_amdgcn_sdot4((int)hi, 0x01010101, isum, false);
+    if (ok[i]) *reinterpret_cast<uint2*>(p.q + rbase + (sub * 64 + lane + i * 64 * WPR) * 8) = make_uint2(lo, hi);
   }
+  if (p.sum) {
+    const int tot = red.isum(isum, 3);
+    if (lane == 0 && sub == 0) vec_store(p.sum, p.vec_dtype, row, (float)tot * scale);
+  }
+  if (!p.static_amax && lane == 0 && sub == 0) vec_store(p.scale, p.vec_dtype, row, scale);
 }
 
 template <bool LN>
 static int launch_rowwise(const RowParams& p, hipStream_t st, const char* what) {
   const int chunks = p.cols / 8;
   const int64_t rows = p.rows;
-  size_t dyn = 0;
-  if (p.had_k) {
-    const int kk = p.had_k > 1 ? ((p.had_k * p.had_k + 3) & ~3) : 0;
-    dyn = (size_t)(chunks <= 256 ? 4 : 1) * (kk + p.cols) * sizeof(float);  // per wave (wave-per-row variants) or per workgroup
-  }
-#define WANQ_RW(WPR, NCH)                                                                       \
-  do {                                                                                          \
-    if (LN && p.nsets > 1)                                                                      \
-      hipLaunchKernelGGL((rowwise_kernel<WPR, NCH, LN, LN>), dim3((unsigned)((WPR) == 1 ? (rows + 3) / 4 : rows)), \
-                         dim3(256), dyn, st, p);                                                \
-    else                                                                                        \
-      hipLaunchKernelGGL((rowwise_kernel<WPR, NCH, LN>), dim3((unsigned)((WPR) == 1 ? (rows + 3) / 4 : rows)), \
-                         dim3(256), dyn, st, p);                                                \
-  } while (0)
+#define WANQ_RW(WPR, NCH) \
+  hipLaunchKernelGGL((rowwise_kernel<WPR, NCH, LN>), dim3((unsigned)((WPR) == 1 ? (rows + 3) / 4 : rows)), dim3(256), 0, st, p)
   if (chunks <= 64) WANQ_RW(1, 1);
   else if (chunks <= 128) WANQ_RW(1, 2);
   else if (chunks <= 192) WANQ_RW(1, 3);
@@ -640,85 +463,6 @@ extern "C" int wanq_weight_quant(const void* w, int w_dtype, const float* delta,
   const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(weight_quant_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, w_dtype, delta, zp, qmin, qmax, q8, deq, rows, cols);
   return check_launch("wanq_weight_quant");
-}
-
-// ------------------------------------------------------------------------------ ViDiT scale + rotate + quantise
-static int check_rotation(const char* what, const float* premul, const float* hadk, int had_k, int cols) {
-  WANQ_REQUIRE(had_k >= 0 && had_k <= 128, WANQ_E_SHAPE, "%s: had_k=%d out of range", what, had_k);
-  if (had_k) {
-    WANQ_REQUIRE(cols == had_k * 128, WANQ_E_SHAPE,
-                 "%s: rotation needs cols == had_k * 128 (cols=%d, had_k=%d): the transform is H_K (x) H_128", what, cols, had_k);
-    WANQ_REQUIRE(had_k == 1 || hadk, WANQ_E_ARG, "%s: hadk matrix required for had_k > 1", what);
-  }
-  (void)premul;
-  return WANQ_OK;
-}
-
-extern "C" int wanq_rotate_quant_rows(const void* x, int x_dtype, const float* premul, const float* hadk, int had_k,
-                                      void* out_fp, int out_dtype, int8_t* q, void* scale, void* sum, int vec_dtype,
-                                      int64_t rows, int cols, int act, void* stream) {
-  WANQ_REQUIRE(x && (q || out_fp), WANQ_E_ARG, "wanq_rotate_quant_rows: need x and at least one of out_fp / q");
-  WANQ_REQUIRE(is_fp(x_dtype) && (!out_fp || is_fp(out_dtype)), WANQ_E_ARG, "wanq_rotate_quant_rows: bad dtype code");
-  WANQ_REQUIRE(!q || (scale && is_vec(vec_dtype)), WANQ_E_ARG, "wanq_rotate_quant_rows: q needs scale and a valid vec dtype");
-  WANQ_REQUIRE(act == 0 || act == 1, WANQ_E_ARG, "wanq_rotate_quant_rows: act must be 0 or 1");
-  if (int e = check_rows_cols("wanq_rotate_quant_rows", rows, cols)) return e;
-  if (int e = check_rotation("wanq_rotate_quant_rows", premul, hadk, had_k, cols)) return e;
-  if (rows == 0) return WANQ_OK;
-  RowParams p{};
-  p.x = x; p.x_dtype = x_dtype; p.out_fp = out_fp; p.out_dtype = out_dtype; p.q = q; p.scale = scale; p.sum = sum;
-  p.vec_dtype = vec_dtype; p.rows = rows; p.cols = cols; p.act = act; p.rows_per_batch = 1;
-  p.premul = premul; p.hadk = hadk; p.had_k = had_k; p.had_div = sqrtf((float)cols);
-  return launch_rowwise<false>(p, (hipStream_t)stream, "wanq_rotate_quant_rows");
-}
-
-extern "C" int wanq_layernorm_rotate_quant_rows(const void* x, int x_dtype, const void* gamma, const void* mshift,
-                                                const void* mscale, int mod_dtype, int64_t mod_stride,
-                                                int64_t rows_per_batch, float eps, const float* premul, const float* hadk,
-                                                int had_k, int8_t* q, void* scale, void* sum, int vec_dtype, int64_t rows,
-                                                int cols, void* stream) {
-  WANQ_REQUIRE(x && q && scale, WANQ_E_ARG, "wanq_layernorm_rotate_quant_rows: NULL pointer");
-  WANQ_REQUIRE(is_fp(x_dtype) && is_vec(vec_dtype), WANQ_E_ARG, "wanq_layernorm_rotate_quant_rows: bad dtype code");
-  WANQ_REQUIRE(!(gamma || mshift || mscale) || is_fp(mod_dtype), WANQ_E_ARG, "wanq_layernorm_rotate_quant_rows: bad mod dtype");
-  WANQ_REQUIRE(rows_per_batch >= 1, WANQ_E_ARG, "wanq_layernorm_rotate_quant_rows: rows_per_batch must be >= 1");
-  if (int e = check_rows_cols("wanq_layernorm_rotate_quant_rows", rows, cols)) return e;
-  if (int e = check_rotation("wanq_layernorm_rotate_quant_rows", premul, hadk, had_k, cols)) return e;
-  if (rows == 0) return WANQ_OK;
-  RowParams p{};
-  p.x = x; p.x_dtype = x_dtype; p.gamma = gamma; p.mshift = mshift; p.mscale = mscale; p.mod_dtype = mod_dtype;
-  p.mod_stride = mod_stride; p.rows_per_batch = rows_per_batch; p.eps = eps; p.q = q; p.scale = scale; p.sum = sum;
-  p.vec_dtype = vec_dtype; p.rows = rows; p.cols = cols;
-  p.premul = premul; p.hadk = hadk; p.had_k = had_k; p.had_div = sqrtf((float)cols);
-  return launch_rowwise<true>(p, (hipStream_t)stream, "wanq_layernorm_rotate_quant_rows");
-}
-
-extern "C" int wanq_layernorm_rotate_quant_rows_multi(const void* x, int x_dtype, const void* gamma, const void* mshift,
-                                                      const void* mscale, int mod_dtype, int64_t mod_stride,
-                                                      int64_t rows_per_batch, float eps, int nsets,
-                                                      const float* const* premul, const float* hadk, int had_k,
-                                                      int8_t* const* q, void* const* scale, void* const* sum, int vec_dtype,
-                                                      int64_t rows, int cols, void* stream) {
-  const char* what = "wanq_layernorm_rotate_quant_rows_multi";
-  WANQ_REQUIRE(nsets >= 1 && nsets <= 3, WANQ_E_ARG, "%s: nsets=%d must be 1..3", what, nsets);
-  WANQ_REQUIRE(x && q && scale && sum && premul, WANQ_E_ARG, "%s: NULL pointer", what);
-  WANQ_REQUIRE(is_fp(x_dtype) && is_vec(vec_dtype), WANQ_E_ARG, "%s: bad dtype code", what);
-  WANQ_REQUIRE(!(gamma || mshift || mscale) || is_fp(mod_dtype), WANQ_E_ARG, "%s: bad mod dtype", what);
-  WANQ_REQUIRE(rows_per_batch >= 1, WANQ_E_ARG, "%s: rows_per_batch must be >= 1", what);
-  if (int e = check_rows_cols(what, rows, cols)) return e;
-  for (int t = 0; t < nsets; ++t) {
-    WANQ_REQUIRE(q[t] && scale[t], WANQ_E_ARG, "%s: set %d: q and scale are required", what, t);
-    if (int e = check_rotation(what, premul[t], hadk, had_k, cols)) return e;
-  }
-  if (rows == 0) return WANQ_OK;
-  RowParams p{};
-  p.x = x; p.x_dtype = x_dtype; p.gamma = gamma; p.mshift = mshift; p.mscale = mscale; p.mod_dtype = mod_dtype;
-  p.mod_stride = mod_stride; p.rows_per_batch = rows_per_batch; p.eps = eps; p.vec_dtype = vec_dtype; p.rows = rows; p.cols = cols;
-  p.hadk = hadk; p.had_k = had_k; p.had_div = sqrtf((float)cols);
-  p.nsets = nsets;
-  p.premul = premul[0]; p.q = q[0]; p.scale = scale[0]; p.sum = sum[0];
-  for (int t = 1; t < nsets; ++t) {
-    p.premul_n[t - 1] = premul[t]; p.q_n[t - 1] = q[t]; p.scale_n[t - 1] = scale[t]; p.sum_n[t - 1] = sum[t];
-  }
-  return launch_rowwise<true>(p, (hipStream_t)stream, what);
 }
 
 // ------------------------------------------------------------------------------ 4-bit weight storage

@@ -82,13 +82,17 @@ def random_hadamard_matrix(size, device, signs=None):
 
 
 def kernel_rotation_params(n, device):
-    """(had_k, hadk fp32 [K,K] or None) for wanq_rotate_quant_rows, i.e. hadU written as (H_K' (x) H_128)/sqrt(n)
-    with K' = K * m/128; None when n has no such form (block size m < 128, e.g. 8960 = 140 x 64)."""
+    """(had_k, hadk fp32 [K',K'] or None) for wanq_rotate_quant_rows, i.e. hadU written as (H_K' (x) H_128)/sqrt(n)
+    with K' = K * m/128.  Only had_k crosses the C boundary (the library generates the same table from n); hadk is returned
+    for host-side checks.  None when the library has no kernel for n: block size m < 128 (8960 = 140 x 64) or a K' outside
+    {2^p <= 32, 12, 40} (csrc/rotate.hip)."""
     hadK, K = get_hadK(n)
     m = n // K
     if m < 128:
         return None
     kk = K * (m // 128)
+    if kk not in (1, 2, 4, 8, 16, 32, 12, 40):
+        return None
     if kk == 1:
         return 1, None
     H = np.kron(hadK.numpy().astype(np.int64) if hadK is not None else np.ones((1, 1), dtype=np.int64), sylvester(m // 128))

@@ -21,7 +21,7 @@ lib = ctypes.CDLL(LIB_PATH)
 
 F16, BF16, F32, I32, I16 = 0, 1, 2, 3, 4
 EPI_GELU, EPI_GATE_RES = 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
@@ -35,9 +35,9 @@ PROTOTYPES = {
     "wanq_row_minmax": [_vp, _i, _vp, _vp, _vp, _i64, _i, _vp],
     "wanq_weight_quant": [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _i64, _i, _vp],
     "wanq_rmsnorm_rope": [_vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _i64, _i64, _f, _vp],
-    "wanq_rotate_quant_rows": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _vp],
-    "wanq_layernorm_rotate_quant_rows": [_vp, _i, _vp, _vp, _vp, _i, _i64, _i64, _f, _vp, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _vp],
-    "wanq_layernorm_rotate_quant_rows_multi": [_vp, _i, _vp, _vp, _vp, _i, _i64, _i64, _f, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _vp],
+    "wanq_rotate_quant_rows": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _vp],
+    "wanq_layernorm_rotate_quant_rows": [_vp, _i, _vp, _vp, _vp, _i, _i64, _i64, _f, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _vp],
+    "wanq_layernorm_rotate_quant_rows_multi": [_vp, _i, _vp, _vp, _vp, _i, _i64, _i64, _f, _i, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _vp],
     "wanq_pack_w4": [_vp, _vp, _i, _i64, _i, _vp],
     "wanq_unpack_w4": [_vp, _vp, _i, _i64, _i, _vp],
     "wanq_attention_fwd": [_vp, _vp, _vp, _vp, _i, _i64, _i64, _i, _i, _i64, _i64, _i64, _i64, _f, _vp],

@@ -216,25 +216,23 @@ def weight_quant(w, delta, zero_point, qmin, qmax, want_int8=True, want_dequant=
 # ---- ViDiT activation transform fused with the quantiser (no counterpart in the reference extension: its kernel mode
 #      skips the transform altogether; simulation mode does x*mask -> x.double() @ R in torch)
 def _rotation_args(premul, rotation, cols, device):
-    had_k, hadk = (0, None) if rotation is None else rotation
+    """rotation: None (no transform: not accepted by the rotate entry points) or (had_k, _) from
+    qdiff.quarot.quarot_utils.kernel_rotation_params; the +-1 table across the 128-wide blocks is a fixed function of the
+    width and lives inside the library, so only had_k = cols / 128 crosses the boundary."""
+    had_k = 0 if rotation is None else rotation[0]
     if premul is not None:
         _C.check_gpu("premul", premul)
         _C.check_dtype("premul", premul, torch.float32)
         _C.check_contig("premul", premul)
         _C.check_shape("premul", premul, cols)
-    if hadk is not None:
-        _C.check_gpu("hadk", hadk)
-        _C.check_dtype("hadk", hadk, torch.float32)
-        _C.check_contig("hadk", hadk)
-        _C.check_shape("hadk", hadk, had_k, had_k)
-    return int(had_k), hadk
+    return int(had_k)
 
 
-def rotate_quant(input, premul, rotation, sum_output, scaling, act=0, out_fp=None, quantize=True):
+def rotate_quant(input, premul, rotation, sum_output, scaling, out_fp=None, quantize=True):
     """y = hadU(input * premul) -> int8 codes (+ scale / sum) and / or the fp result in `out_fp`.
-    rotation: None or (had_k, hadk fp32 [had_k, had_k] | None) from qdiff.quarot.quarot_utils.kernel_rotation_params."""
+    rotation: (had_k, _) from qdiff.quarot.quarot_utils.kernel_rotation_params."""
     rows, cols = _rows_cols("input", input)
-    had_k, hadk = _rotation_args(premul, rotation, cols, input.device)
+    had_k = _rotation_args(premul, rotation, cols, input.device)
     q = None
     if quantize:
         _check_vec("scaling", scaling, rows)
@@ -244,17 +242,17 @@ def rotate_quant(input, premul, rotation, sum_output, scaling, act=0, out_fp=Non
     if out_fp is not None:
         _rows_cols("out_fp", out_fp)
     with torch.cuda.device(input.device):
-        _C.call("wanq_rotate_quant_rows", _C.ptr(input), _C.dt(input), _C.ptr(premul), _C.ptr(hadk), had_k,
+        _C.call("wanq_rotate_quant_rows", _C.ptr(input), _C.dt(input), _C.ptr(premul), had_k,
                 _C.ptr(out_fp), _C.dt(out_fp) if out_fp is not None else _C.F32, _C.ptr(q),
                 _C.ptr(scaling) if quantize else None, _C.ptr(sum_output) if quantize else None,
-                _C.dt(scaling) if quantize else _C.F32, rows, cols, act, _C.stream())
+                _C.dt(scaling) if quantize else _C.F32, rows, cols, _C.stream())
     return q
 
 
 def layernorm_rotate_quant(output, input, weight, shift_msa, scale_msa, premul, rotation, sum_output, scaling, epsilon):
     """layernorm_nobias_t2i_quant_sum_fuse with the ViDiT transform between the modulation and the quantiser."""
     rows, cols = _rows_cols("input", input)
-    had_k, hadk = _rotation_args(premul, rotation, cols, input.device)
+    had_k = _rotation_args(premul, rotation, cols, input.device)
     _C.check_gpu("output", output)
     _C.check_dtype("output", output, torch.int8)
     _C.check_contig("output", output)
@@ -278,7 +276,7 @@ def layernorm_rotate_quant(output, input, weight, shift_msa, scale_msa, premul, 
                 raise RuntimeError("shift_msa / scale_msa must be [batch, cols] views with equal strides")
     with torch.cuda.device(input.device):
         _C.call("wanq_layernorm_rotate_quant_rows", _C.ptr(input), _C.dt(input), _C.ptr(weight), _C.ptr(shift_msa),
-                _C.ptr(scale_msa), _C.F32, mod_stride, rows // batch, float(epsilon), _C.ptr(premul), _C.ptr(hadk), had_k,
+                _C.ptr(scale_msa), _C.F32, mod_stride, rows // batch, float(epsilon), _C.ptr(premul), had_k,
                 _C.ptr(output), _C.ptr(scaling), _C.ptr(sum_output), _C.dt(scaling), rows, cols, _C.stream())
 
 
@@ -290,9 +288,9 @@ def layernorm_rotate_quant_multi(outputs, input, weight, shift_msa, scale_msa, p
     if not (1 <= n <= 3 and len(premuls) == n and len(sum_outputs) == n and len(scalings) == n):
         raise RuntimeError("layernorm_rotate_quant_multi: 1..3 sets, lists of equal length")
     rows, cols = _rows_cols("input", input)
-    had_k, hadk = 0, None
+    had_k = 0
     for t in range(n):
-        had_k, hadk = _rotation_args(premuls[t], rotation, cols, input.device)
+        had_k = _rotation_args(premuls[t], rotation, cols, input.device)
         _C.check_gpu("output", outputs[t])
         _C.check_dtype("output", outputs[t], torch.int8)
         _C.check_contig("output", outputs[t])
@@ -318,7 +316,7 @@ def layernorm_rotate_quant_multi(outputs, input, weight, shift_msa, scale_msa, p
                 raise RuntimeError("shift_msa / scale_msa must be [batch, cols] views with equal strides")
     with torch.cuda.device(input.device):
         _C.call("wanq_layernorm_rotate_quant_rows_multi", _C.ptr(input), _C.dt(input), _C.ptr(weight), _C.ptr(shift_msa),
-                _C.ptr(scale_msa), _C.F32, mod_stride, rows // batch, float(epsilon), n, _C.ptr_array(premuls), _C.ptr(hadk),
+                _C.ptr(scale_msa), _C.F32, mod_stride, rows // batch, float(epsilon), n, _C.ptr_array(premuls),
                 had_k, _C.ptr_array(outputs), _C.ptr_array(scalings), _C.ptr_array(sum_outputs), _C.dt(scalings[0]), rows, cols,
                 _C.stream())
     return outputs
