@@ -52,21 +52,30 @@ class GemmTimer(list):
         return dict(launches=len(self), seconds=t, ops=ops)
 
 
-def pmc_traffic(which):
-    """HBM bytes per launch for `which` in {"gemm", "attention"} from the newest committed profiles/*_<which>_traffic.json
-    (written by tools/{gemm,attn}_traffic_summary.py from rocprofv3 --pmc passes); None if no summary is committed."""
+def pmc_traffic(which, workload_key):
+    """(HBM bytes per launch, source) for `which` in {"gemm", "attention"} from the newest committed
+    profiles/*_<which>_traffic.json (written by tools/{gemm,attn}_traffic_summary.py from separate rocprofv3 --pmc passes:
+    counters cannot be read inside this process).  The summary names the workload it was taken on; when that is not the
+    workload being timed now the figure does not apply and (None, reason) is returned."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{which}_traffic.json")))
     if not files:
-        return None
+        return None, "no committed PMC summary"
     with open(files[-1]) as fh:
-        return json.load(fh)["hbm_bytes_per_launch"]
+        d = json.load(fh)
+    src = "profiles/" + os.path.basename(files[-1])
+    if d.get("workload", "t2v-1.3B 832*480 81f n1") != workload_key:
+        return None, f"{src} was taken on '{d.get('workload', 't2v-1.3B 832*480 81f n1')}', not on this run's '{workload_key}'"
+    return d["hbm_bytes_per_launch"], src + (f" ({d['code']})" if "code" in d else "")
 
 
-def cpu_baseline(cfg, L, rows=1024, reps=3):
-    """Reference fake-quant path (oracle/wan_ref.py, torch-CPU fp32) on a bounded slice of the SAME workload:
-    `rows` query tokens of one DiT block at sequence length L (all ten fake-quant Linears on those tokens, fp32
-    attention of rows x L keys), scaled by L/rows x blocks x 2 passes to one denoising step."""
+def cpu_baseline(cfg, L, n_vidit_per_block=3, rows=1024, reps=3):
+    """Reference fake-quant path (oracle/wan_ref.py, torch-CPU fp32; ViDiT layers with the reference's fp64 rotation
+    GEMM, Q/viditq/viditq_quant_layer.py:62-63) on a bounded sample of the SAME workload: `rows` query tokens of one DiT
+    block at sequence length L (all ten fake-quant Linears on those tokens, fp32 attention of rows x L keys), scaled by
+    L/rows x blocks x 2 passes to one denoising step.  Beside it `cfg_a`: one WHOLE block of cfg-A (9 frames, L = 4680:
+    BASELINE config 1, the reference's own CPU-runnable case), all tokens, scaled by blocks x 2 passes only."""
+    from oracle import qdiff_ref as qr
     from oracle import wan_ref as wr
 
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
@@ -82,18 +91,36 @@ def cpu_baseline(cfg, L, rows=1024, reps=3):
     for n in ("self_attn.norm_q", "self_attn.norm_k", "cross_attn.norm_q", "cross_attn.norm_k"):
         sd[n + ".weight"] = torch.ones(C)
     sd["norm3.weight"], sd["norm3.bias"], sd["modulation"] = torch.ones(C), torch.zeros(C), torch.randn(1, 6, C, generator=g) / C ** 0.5
-    blk = wr.block_from_state(sd, H, quant=True)
+    vidit = None
+    if n_vidit_per_block:  # self-attention q / k / v carry the ViDiT scale + rotate, as in the GPU workload
+        import numpy as np
+        vidit = {}
+        for n in ("self_attn.q", "self_attn.k", "self_attn.v"):
+            signs = (torch.randint(0, 2, (C,), generator=g) * 2 - 1).double().numpy()
+            R = torch.from_numpy(np.ascontiguousarray(qr.hadamard_from_signs(signs)))
+            vidit[n] = (torch.rand(C, generator=g) + 0.5, R)
+    blk = wr.block_from_state(sd, H, quant=True, vidit=vidit)
     d = C // H
-    x = torch.randn(rows, C, generator=g)
     e0 = torch.randn(1, 6, C, generator=g) * 0.1
     ctx = torch.randn(512, C, generator=g)
+    freqs = wr.rope_freqs(d)
+
+    def median_time(fn):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2]
+
+    # ---- (1) the timed workload's sequence length: a row slice against full-length keys / values
+    x = torch.randn(rows, C, generator=g)
     kf = torch.randn(L, H, d, generator=g)
     vf = torch.randn(L, H, d, generator=g)
-    freqs = wr.rope_freqs(d)
     grid = (1, 16, rows // 16)
 
     def slice_pass():
-        # self-attention of the slice against full-length keys/values, then the rest of the block on the slice
         e = [t.reshape(1, C) for t in (blk.mod + e0).chunk(6, dim=1)]
         h = wr.layer_norm(x, blk.eps) * (1 + e[1]) + e[0]
         q = wr.rms_norm(blk.lin["self_attn.q"](h), blk.norm_w["self_attn.norm_q"], blk.eps).view(rows, H, d)
@@ -111,17 +138,20 @@ def cpu_baseline(cfg, L, rows=1024, reps=3):
         h = wr.layer_norm(y, blk.eps) * (1 + e[4]) + e[3]
         return y + blk.lin["ffn.2"](torch.nn.functional.gelu(blk.lin["ffn.0"](h), approximate="tanh")) * e[5]
 
-    slice_pass()
-    ts = []
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        slice_pass()
-        ts.append(time.perf_counter() - t0)
-    t_slice = sorted(ts)[len(ts) // 2]
+    t_slice = median_time(slice_pass)
     step_s = t_slice * (L / rows) * cfg["num_layers"] * 2
+    # ---- (2) cfg-A: one whole block, every token (grid 3 x 30 x 52 = 4680 tokens)
+    grid_a = (3, 30, 52)
+    La = grid_a[0] * grid_a[1] * grid_a[2]
+    xa = torch.randn(La, C, generator=g)
+    t_blk = median_time(lambda: blk(xa, e0, grid_a, La, ctx, freqs))
+    step_a = t_blk * cfg["num_layers"] * 2
+    vd = f"ViDiT scale + fp64 rotation on {n_vidit_per_block} of them" if n_vidit_per_block else "no ViDiT layers"
     return dict(value=1.0 / step_s, unit="steps/s", cores=cores, kind="port",
-                sample=f"{rows}-token row slice of one fake-quant DiT block at L={L} (10 fake-quant Linears + fp32 attention "
-                       f"{rows}x{L}x{H} heads), median of {reps}: {t_slice:.3f}s, scaled x{L / rows:.1f} x{cfg['num_layers']} blocks x2 passes")
+                sample=f"{rows}-token row slice of one fake-quant DiT block at L={L} (10 fake-quant Linears, {vd}, + fp32 "
+                       f"attention {rows}x{L}x{H} heads), median of {reps}: {t_slice:.3f}s, scaled x{L / rows:.1f} x{cfg['num_layers']} blocks x2 passes",
+                cfg_a={"value": 1.0 / step_a, "unit": "steps/s", "workload": f"832*480 9f (L={La})",
+                       "sample": f"one whole fake-quant block on all {La} tokens, median of {reps}: {t_blk:.3f}s, scaled x{cfg['num_layers']} blocks x2 passes"})
 
 
 def main():
@@ -137,7 +167,12 @@ def main():
     ap.add_argument("--no-quality", action="store_true")
     ap.add_argument("--quant-config", dest="quant_config", default="w8a8_all_linears.yaml", help="file under quant_configs/")
     ap.add_argument("--no-cfg-parallel", action="store_true", help="pure Ulysses over all GPUs (needs heads %% N == 0)")
+    ap.add_argument("--preset", default=os.environ.get("WANQ_BENCH_PRESET", ""), choices=["", "14B-ulysses"],
+                    help="14B-ulysses = the second north-star target: --model t2v-14B --size 1280*720 --no-cfg-parallel "
+                         "(Ulysses degree = N; also selectable with WANQ_BENCH_PRESET in the environment)")
     args = ap.parse_args()
+    if args.preset == "14B-ulysses":
+        args.model, args.size, args.no_cfg_parallel = "t2v-14B", "1280*720", True
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -145,7 +180,7 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the quantized hot path has no CPU fallback)"
     # Rehearsal of the N > 1 control flow on a ONE-GPU box (RCCL refuses two ranks on one device): all ranks share cuda:0,
-    # rendezvous over gloo, and the collectives are staged through host memory by the test scaffolding.  Never a measurement.
+    # rendezvous over gloo, and the collectives are staged through host memory (wan/distributed/rehearsal.py).  Never a measurement.
     rehearse = world > 1 and os.environ.get("WANQ_BENCH_REHEARSE_ON_ONE_GPU") == "1"
     if rehearse:
         local = 0
@@ -153,9 +188,8 @@ def main():
     dev = torch.device("cuda", local)
     if rehearse:
         dist.init_process_group("gloo", init_method="env://")
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from sp_rehearsal_worker import _stage_collectives
-        _stage_collectives()
+        from wan.distributed.rehearsal import stage_collectives_through_host
+        stage_collectives_through_host()
     elif world > 1:
         dist.init_process_group("nccl", init_method="env://", device_id=dev)
 
@@ -177,7 +211,7 @@ def main():
     ctx_u = torch.randn(512, cfg["text_dim"], generator=g, device=dev) * 0.1
     total = args.steps + args.warmup
     sched = FlowUniPCMultistepScheduler(cfg["num_train_timesteps"], shift=1.0)  # the reference's default solver
-    sched.set_timesteps(max(total, 30), device=dev, shift=5.0)
+    sched.set_timesteps(max(total + args.steps, 30), device=dev, shift=5.0)  # + the instrumented repeat of the K steps
 
     # ---- the reference's flow on the synthetic model: FP model -> quant_layer_refactor (config) -> calibration pass
     #      (per-channel absmax hooks) -> channel masks + rotations (ptq) -> kernel mode (quant_generate, if_hardware)
@@ -221,14 +255,10 @@ def main():
     latent = latent0
     for i in range(args.warmup):
         latent = step(latent, i)
-    timer = GemmTimer()
-    atimer = GemmTimer()
     from wan import ops as wan_ops
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    qgemm.set_timer(timer)
-    wan_ops.set_attention_timer(atimer)
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         latent = step(latent, i)
@@ -236,43 +266,62 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    qgemm.set_timer(None)
-    wan_ops.set_attention_timer(None)
     if world > 1:
         tmax = torch.tensor([dt], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
     assert torch.isfinite(latent).all(), "non-finite latent after the timed steps"
 
+    # ---- per-kernel timing for the roofline objects: the same K steps once more, with a HIP event pair around every GEMM /
+    # attention launch on the launch stream (about 1400 pairs per step, which is why they stay out of the headline region
+    # above; `instrumented_ms_per_step` shows what they cost).  share_of_step = kernel time / wall time of THIS region.
+    timer = GemmTimer()
+    atimer = GemmTimer()
+    qgemm.set_timer(timer)
+    wan_ops.set_attention_timer(atimer)
+    torch.cuda.synchronize()
+    tp0 = time.perf_counter()
+    for i in range(total, total + args.steps):
+        latent = step(latent, i)
+    torch.cuda.synchronize()
+    dt_prof = time.perf_counter() - tp0
+    qgemm.set_timer(None)
+    wan_ops.set_attention_timer(None)
+
     gs = timer.summary()
     out = {
         "metric": "denoising steps/sec Wan2.1-%s W8A8 %sx%df" % (args.model.split("-")[-1], args.size.replace("*", "x"), args.frames), "value": args.steps / dt, "unit": "steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "instrumented_ms_per_step": dt_prof / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
         "config": {"workload": f"Wan2.1-{args.model} DiT, {n_quant} Linears W8A8 (W asym per-channel static, A sym per-token dynamic; "
                                f"ViDiT-Q scale+rotate alpha=0.5665 on {n_vidit} self-attn q/k/v layers), "
                                f"{args.size}x{args.frames}f, latent {list(shape)}, L={seq_len}, cond+uncond+CFG+scheduler per step",
-                   "quant_config": args.quant_config, "attention": "bf16", "parallelism": plan.describe()},
+                   "quant_config": args.quant_config, "attention": "bf16", "parallelism": plan.describe(),
+                   "rccl_ranks": dist.get_world_size() if world > 1 else 1},
     }
     # Two MFMA-bound kernels carry the step: the bf16 flash attention (the dominant one at L = 32760) and the int8 GEMM
     # behind every W8A8 Linear.  `roofline` is whichever took more of the timed region; the other is reported beside it.
     # `traffic`: HBM bytes per launch from the committed PMC passes (profiles/*_traffic.json: FETCH_SIZE x2 + WRITE_SIZE,
     # one counter per rocprofv3 pass, averaged over the same launch mix); counters cannot be read inside this process.
     lines = []
+    wkey = f"{args.model} {args.size} {args.frames}f n{world}"
+    g_traffic, g_src = pmc_traffic("gemm", wkey)
+    a_traffic, a_src = pmc_traffic("attention", wkey)
     if gs:
         ach = gs["ops"] / gs["seconds"]
         lines.append({"bound": "mfma", "kernel": "gemm_w8a8_big_kernel / gemm_w8a8_kernel (int8 MFMA, every W8A8 linear)",
                       "achieved": ach / 1e12, "peak": INT8_MFMA_PEAK / 1e12, "unit": "TOP/s", "frac": ach / INT8_MFMA_PEAK,
-                      "traffic": pmc_traffic("gemm"), "traffic_unit": "HBM bytes per launch (PMC)", "launches": gs["launches"],
-                      "avg_launch_us": gs["seconds"] / gs["launches"] * 1e6, "share_of_step": gs["seconds"] / dt})
+                      "traffic": g_traffic, "traffic_source": g_src, "traffic_unit": "HBM bytes per launch (PMC)", "launches": gs["launches"],
+                      "avg_launch_us": gs["seconds"] / gs["launches"] * 1e6, "share_of_step": gs["seconds"] / dt_prof})
     asum = atimer.summary()
     if asum:
         ach = asum["ops"] / asum["seconds"]
         lines.append({"bound": "mfma", "kernel": "attn_fwd_kernel (bf16 MFMA flash attention, self + cross)", "achieved": ach / 1e12,
                       "peak": BF16_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK,
-                      "traffic": pmc_traffic("attention"), "traffic_unit": "HBM bytes per launch (PMC)",
+                      "traffic": a_traffic, "traffic_source": a_src, "traffic_unit": "HBM bytes per launch (PMC)",
                       "launches": asum["launches"], "avg_launch_us": asum["seconds"] / asum["launches"] * 1e6,
-                      "share_of_step": asum["seconds"] / dt})
+                      "share_of_step": asum["seconds"] / dt_prof})
     lines.sort(key=lambda r: -r["share_of_step"])
     if lines:
         out["roofline"] = lines[0]
@@ -290,7 +339,7 @@ def main():
         out["quality"] = {"tensor": "DiT output latent (noise_pred)", "rel_l2_vs_fp": ((yq - yf).norm() / yf.norm()).item(),
                           "psnr_db_vs_fp": 10 * torch.log10(torch.tensor(rng * rng / mse)).item()}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # reported at N = 1 only
-        out["cpu_baseline"] = cpu_baseline(cfg, seq_len)
+        out["cpu_baseline"] = cpu_baseline(cfg, seq_len, n_vidit_per_block=n_vidit // max(1, cfg["num_layers"]))
     if rank == 0:
         if rehearse:
             out["data"] = "REHEARSAL on one GPU (not a measurement)"

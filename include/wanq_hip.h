@@ -116,6 +116,13 @@ int wanq_row_minmax(const void* w, int w_dtype, float* row_min, float* row_max, 
 int wanq_weight_quant(const void* w, int w_dtype, const float* delta, const float* zp, int qmin, int qmax,
                       int8_t* q8, float* deq, int64_t rows, int cols, void* stream);
 
+/* Reference-format int8 export of a weight matrix, all arithmetic in HALF precision as the reference does it:
+ *   q8 = clamp( round( f16(w) / delta ) - zp, -128, 127 )   delta, zp: fp16 [rows]
+ * Replaces quantize_and_save_weight_ (ViDiT-Q/examples/Wan2.1/wan/quant_wanx_cuda.py:39-53); bit-identical to it
+ * (tests/golden a12_*).  The codes feed `int_weight.pt` written with reference_format=True. */
+int wanq_weight_export_f16(const void* w, int w_dtype, const void* delta_f16, const void* zp_f16, int8_t* q8,
+                           int64_t rows, int cols, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Attention front-end for q / k:  y = x * rsqrt(mean(x^2) + eps) * weight   (RMSNorm over ALL cols),
  * then the 3-axis rotary embedding per head: pairs (2i, 2i+1) of every head are multiplied by
@@ -154,7 +161,8 @@ int wanq_attention_fwd_split(const void* q, const void* k, const void* v, void* 
  * ViDiT activation transform fused with the per-token quantiser:
  *   y = hadU(x * premul),   hadU = (H_K (x) H_128) / sqrt(cols)   (natural-order Walsh-Hadamard on each
  *   128-wide block, then the reference's +-1 table of order K across blocks)
- * premul fp32[cols] = channel_mask * rotation_signs (either may be all ones), or NULL.  had_k must equal cols / 128
+ * premul fp32[cols] = channel_mask * rotation_signs (either may be all ones), or NULL.  had_k = 0: no rotation, y = x * premul
+ * (SmoothQuant, any cols % 8 == 0); otherwise had_k must equal cols / 128
  * (the caller states the factorisation it expects); the table across blocks is the one get_hadK picks for this width
  * (ViDiT-Q/quant_utils/qdiff/quarot/quarot_utils.py:100-155), a fixed function of cols: Sylvester for 2^p (had_k <= 32),
  * Paley-I of order 12 for 1536, H_2 (x) Paley-I of order 20 for 5120 -- generated inside the library, not passed in.

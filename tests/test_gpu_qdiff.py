@@ -221,3 +221,67 @@ def test_surgery_save_load_roundtrip_and_mixed_precision():
     deq = qr.static_fake_quant(f.fp_module.weight.data.cpu().numpy(), 4, False)[0]
     assert np.array_equal(f.weight.data.cpu().numpy(), deq)
     assert torch.isfinite(m3(x)).all()
+
+
+@pytest.mark.parametrize("name", ["a1_static_16x64", "a1_static_1536x1536"])
+def test_reference_format_export_vs_reference_golden(golden, name):
+    """wanq_weight_export_f16 == quantize_and_save_weight_ of the reference (W/wan/quant_wanx_cuda.py:39-53), bit for bit:
+    fp16 weight / fp16 delta in half arithmetic, minus the fp16 zero point, clamped to int8 (fixture a12_*, generated by the
+    reference's own four-line equation on the reference quantizer's delta / zero_point)."""
+    import os
+
+    import viditq_extension.fused as fused
+
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", name + ".npz")):
+        pytest.skip("fixture not present")
+    g = golden(name)
+    if "a12_int_weight" not in g:
+        pytest.skip("fixture carries no a12 vectors")
+    w = t(g["w"], torch.float32)
+    s16 = torch.from_numpy(g["a12_scale_f16"]).to(DEV)
+    z16 = torch.from_numpy(g["a12_zp_f16"]).to(DEV)
+    assert s16.dtype == torch.float16 and z16.dtype == torch.float16
+    q = fused.weight_export_f16(w, s16, z16)
+    assert np.array_equal(q.cpu().numpy(), g["a12_int_weight"])
+    # a fp16 copy of the weight gives the same codes (the equation starts by casting the weight to half)
+    assert torch.equal(fused.weight_export_f16(w.half(), s16, z16), q)
+
+
+def test_refresh_keeps_rotated_weights_consistent_under_mixed_precision():
+    """bitwidth_refactor_ on a ViDiT layer: after the weight drops to 4 bit, the integer codes must still be
+    those of the scaled + rotated weight (the activations keep being rotated), i.e. refresh() takes the layer's own PTQ
+    derivation.  Checked against the fake-quant oracle with the same mask / signs at 4 bit."""
+    import torch.nn as nn
+
+    from qdiff import config as qcfg
+    from qdiff.base.quant_model import bitwidth_refactor_, quant_layer_refactor_
+    from qdiff.utils import apply_func_to_submodules
+
+    n, N = 1536, 96
+    torch.manual_seed(5)
+    holder = nn.ModuleDict({"ffn": nn.Linear(n, N)}).to(DEV)
+    c = qcfg.create({"weight": {"n_bits": [4, 8], "i_bitwidth": 1, "sym": False}, "act": {"n_bits": 8, "sym": True},
+                     "viditq": {"alpha": 0.5665, "layer_name_regex": ""},
+                     "mixed_precision": {"weight": {"layer_name_regex": ["", "ffn", ""]}, "act": {"layer_name_regex": ["", ""]}}})
+    apply_func_to_submodules(holder, nn.Linear, quant_layer_refactor_, name=None, parent_module=None, quant_config=c,
+                             full_name=None, remain_fp_regex=None)
+    lin = holder["ffn"]
+    g = torch.Generator().manual_seed(6)
+    act_mask = torch.rand(n, generator=g) * 3 + 0.2
+    lin.get_channel_mask(act_mask.to(DEV))
+    lin.get_rotation_matrix(g)
+    lin.update_quantized_weight_rotated_and_scaled()
+    apply_func_to_submodules(holder, type(lin), bitwidth_refactor_, name=None, parent_module=None, quant_config=c, full_name=None)
+    assert lin.w_quantizer.n_bits == 4 and lin.int_weight.min() >= -8 and lin.int_weight.max() <= 7
+    R = qr.hadamard_from_signs(lin.rotation_signs.numpy())
+    w = lin.fp_module.weight.data.cpu().numpy()
+    mask = lin.channel_mask.cpu().numpy()
+    w_final = qr.vidit_weight(w, mask, R, 4, False)
+    w_final = w_final[0] if isinstance(w_final, tuple) else w_final
+    got = lin.weight.data.cpu().numpy()
+    assert np.abs(got - w_final).max() <= 1e-6 * np.abs(w_final).max() + 1e-7, np.abs(got - w_final).max()
+    x = torch.randn(40, n, generator=g) * 2
+    y = lin(x.to(DEV))
+    ref = qr.vidit_linear(x.numpy()[None], w_final, lin.bias.detach().cpu().numpy(), mask, R)
+    ref = ref[0] if ref.ndim == 3 else ref
+    assert np.abs(y.cpu().numpy() - ref).max() < 2e-2 * np.abs(ref).max()

@@ -482,6 +482,9 @@ extern "C" int wanq_rotate_quant_rows(const void* x, int x_dtype, const float* p
   WANQ_REQUIRE(x && (q || out_fp), WANQ_E_ARG, "%s: need x and at least one of out_fp / q", what);
   WANQ_REQUIRE(is_fp(x_dtype) && (!out_fp || is_fp(out_dtype)), WANQ_E_ARG, "%s: bad dtype code", what);
   WANQ_REQUIRE(!q || (scale && is_vec(vec_dtype)), WANQ_E_ARG, "%s: q needs scale and a valid vec dtype", what);
+  if (had_k == 0)  // channel scale only
+    return premul_quant_rows(false, x, x_dtype, nullptr, nullptr, nullptr, 0, 1, 0.f, premul, out_fp, out_dtype, q, scale, sum,
+                             vec_dtype, rows, cols, (hipStream_t)stream, what);
   if (int e = check_rows(what, rows)) return e;
   if (int e = check_rotation(what, had_k, cols)) return e;
   if (rows == 0) return WANQ_OK;
@@ -512,6 +515,13 @@ extern "C" int wanq_layernorm_rotate_quant_rows(const void* x, int x_dtype, cons
                                                 void* scale, void* sum, int vec_dtype, int64_t rows, int cols, void* stream) {
   const char* what = "wanq_layernorm_rotate_quant_rows";
   WANQ_REQUIRE(q && scale, WANQ_E_ARG, "%s: NULL pointer", what);
+  if (had_k == 0) {  // channel scale only
+    RotParams chk{};
+    if (int e = fill_ln(chk, what, x, x_dtype, gamma, mshift, mscale, mod_dtype, mod_stride, rows_per_batch, eps, vec_dtype, rows, cols))
+      return e;
+    return premul_quant_rows(true, x, x_dtype, gamma, mshift, mscale, mod_stride, rows_per_batch, eps, premul, nullptr, WANQ_F32, q,
+                             scale, sum, vec_dtype, rows, cols, (hipStream_t)stream, what);
+  }
   if (int e = check_rows(what, rows)) return e;
   if (int e = check_rotation(what, had_k, cols)) return e;
   RotParams p{};
@@ -532,6 +542,15 @@ extern "C" int wanq_layernorm_rotate_quant_rows_multi(const void* x, int x_dtype
   const char* what = "wanq_layernorm_rotate_quant_rows_multi";
   WANQ_REQUIRE(nsets >= 1 && nsets <= 3, WANQ_E_ARG, "%s: nsets=%d must be 1..3", what, nsets);
   WANQ_REQUIRE(q && scale && sum && premul, WANQ_E_ARG, "%s: NULL pointer", what);
+  if (had_k == 0) {  // channel scale only: one pass per set
+    for (int t = 0; t < nsets; ++t) {
+      WANQ_REQUIRE(q[t] && scale[t], WANQ_E_ARG, "%s: set %d: q and scale are required", what, t);
+      if (int e = wanq_layernorm_rotate_quant_rows(x, x_dtype, gamma, mshift, mscale, mod_dtype, mod_stride, rows_per_batch, eps,
+                                                   premul[t], 0, q[t], scale[t], sum[t], vec_dtype, rows, cols, stream))
+        return e;
+    }
+    return WANQ_OK;
+  }
   if (int e = check_rows(what, rows)) return e;
   if (int e = check_rotation(what, had_k, cols)) return e;
   RotParams p{};

@@ -35,6 +35,7 @@ struct RowParams {
   int cols;
   int act;
   int static_amax;
+  const float* premul;  // [cols] fp32 multiplier applied before quantisation (SmoothQuant channel mask), or NULL
 };
 
 __device__ __forceinline__ void load8_rt(const void* base, int dt, int64_t elem, float (&v)[8]) {
@@ -156,6 +157,16 @@ __global__ __launch_bounds__(256) void rowwise_kernel(const RowParams p) {
       for (int j = 0; j < 8; ++j) v[i][j] = gelu_tanh_f32(v[i][j]);
   }
 
+  if (p.premul) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (ok[i]) {
+        float pm[8];
+        Io<F32>::load8(p.premul, (sub * 64 + lane + i * 64 * WPR) * 8, pm);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] *= pm[j];
+      }
+  }
   if (p.out_fp) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
@@ -363,9 +374,63 @@ __global__ __launch_bounds__(256) void weight_quant_kernel(const void* w, int dt
   }
 }
 
+// x * premul (-> LayerNorm + modulate first when `ln`) -> fp output and / or int8 quantise: the transform entry points of
+// rotate.hip with had_k == 0 (channel scale without rotation: SmoothQuant, Q/smooth_quant/sq_quant_layer.py:52-60).
+int premul_quant_rows(bool ln, const void* x, int x_dtype, const void* gamma, const void* mshift, const void* mscale,
+                      int64_t mod_stride, int64_t rows_per_batch, float eps, const float* premul, void* out_fp, int out_dtype,
+                      int8_t* q, void* scale, void* sum, int vec_dtype, int64_t rows, int cols, hipStream_t st, const char* what) {
+  if (int e = check_rows_cols(what, rows, cols)) return e;
+  if (rows == 0) return WANQ_OK;
+  RowParams p{};
+  p.x = x; p.x_dtype = x_dtype; p.gamma = gamma; p.mshift = mshift; p.mscale = mscale; p.mod_dtype = WANQ_F32;
+  p.mod_stride = mod_stride; p.rows_per_batch = rows_per_batch; p.eps = eps; p.out_fp = out_fp; p.out_dtype = out_dtype;
+  p.q = q; p.scale = scale; p.sum = sum; p.vec_dtype = vec_dtype; p.rows = rows; p.cols = cols; p.premul = premul;
+  return ln ? launch_rowwise<true>(p, st, what) : launch_rowwise<false>(p, st, what);
+}
+
+// ------------------------------------------------------------------------------ reference-format int8 export
+// quantize_and_save_weight_ (W/wan/quant_wanx_cuda.py:39-53): everything in HALF precision --
+//   int8 = clamp( round( f16(w) / f16(delta) ) - f16(zp), -128, 127 )
+// torch evaluates the fp16 quotient as fl16(fl32(a / b)); round() and the subtraction are exact on these magnitudes.
+__global__ __launch_bounds__(256) void weight_export_f16_kernel(const void* w, int dt, const __half* delta, const __half* zp,
+                                                                int8_t* q8, int64_t rows, int cols) {
+  const int cpr = cols / 8;
+  const int64_t total = rows * (int64_t)cpr;
+  for (int64_t ch = (int64_t)blockIdx.x * 256 + threadIdx.x; ch < total; ch += (int64_t)gridDim.x * 256) {
+    const int64_t row = ch / cpr;
+    const int c0 = (int)(ch - row * cpr) * 8;
+    float v[8];
+    load8_rt(w, dt, row * cols + c0, v);
+    const float d = __half2float(delta[row]), z = __half2float(zp[row]);
+    int qi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float w16 = __half2float(__float2half_rn(v[j]));        // fp_module.weight.to(torch.float16)
+      const float quo = __half2float(__float2half_rn(w16 / d));     // fp16 division
+      const float t = __half2float(__float2half_rn(rintf(quo) - z));
+      qi[j] = (int)fminf(fmaxf(t, -128.f), 127.f);
+    }
+    *reinterpret_cast<uint2*>(q8 + row * cols + c0) =
+        make_uint2(pack4_i8(qi[0], qi[1], qi[2], qi[3]), pack4_i8(qi[4], qi[5], qi[6], qi[7]));
+  }
+}
+
 }  // namespace wanq
 
 using namespace wanq;
+
+extern "C" int wanq_weight_export_f16(const void* w, int w_dtype, const void* delta_f16, const void* zp_f16, int8_t* q8,
+                                      int64_t rows, int cols, void* stream) {
+  WANQ_REQUIRE(w && delta_f16 && zp_f16 && q8, WANQ_E_ARG, "wanq_weight_export_f16: NULL pointer");
+  WANQ_REQUIRE(is_fp(w_dtype), WANQ_E_ARG, "wanq_weight_export_f16: bad dtype %d", w_dtype);
+  if (int e = check_rows_cols("wanq_weight_export_f16", rows, cols)) return e;
+  if (rows == 0) return WANQ_OK;
+  const int64_t total = rows * (cols / 8);
+  const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(weight_export_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, w_dtype,
+                     static_cast<const __half*>(delta_f16), static_cast<const __half*>(zp_f16), q8, rows, cols);
+  return check_launch("wanq_weight_export_f16");
+}
 
 extern "C" int wanq_quant_rows(const void* x, int x_dtype, int8_t* q, void* scale, void* sum, int vec_dtype,
                                int64_t rows, int cols, int act, int static_amax, void* stream) {

@@ -31,6 +31,11 @@ inline int check_launch(const char* what) {
   return WANQ_OK;
 }
 
+// rowwise.hip: scale-only form of the transform entry points (had_k == 0)
+int premul_quant_rows(bool ln, const void* x, int x_dtype, const void* gamma, const void* mshift, const void* mscale,
+                      int64_t mod_stride, int64_t rows_per_batch, float eps, const float* premul, void* out_fp, int out_dtype,
+                      int8_t* q, void* scale, void* sum, int vec_dtype, int64_t rows, int cols, hipStream_t st, const char* what);
+
 inline bool is_fp(int dt) { return dt == WANQ_F16 || dt == WANQ_BF16 || dt == WANQ_F32; }
 inline bool is_vec(int dt) { return dt == WANQ_F16 || dt == WANQ_F32; }
 

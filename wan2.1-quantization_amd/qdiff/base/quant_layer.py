@@ -56,16 +56,23 @@ class QuantizedLinear(nn.Linear):
         self.int_weight = codes
 
     def refresh(self):
-        """Re-derive everything that depends on quantizer parameters (after bitwidth_refactor / load)."""
-        if self.w_quantizer is not None:
+        """Re-derive the quantized weight after the quantizer changed (bitwidth_refactor, load): the SAME derivation the
+        layer's PTQ step uses -- scale / rotate / double quantisation for the SmoothQuant / QuaRot / ViDiT variants once
+        their mask / rotation exist (as load_quant_param_dict_ dispatches) -- so that the integer codes always match the
+        transform forward() applies to the activations."""
+        if self.w_quantizer is None:
+            return
+        if self.uses_mask and self.uses_rotation and self.channel_mask is not None and self.rotation_signs is not None:
+            self.update_quantized_weight_rotated_and_scaled()
+        elif self.uses_rotation and not self.uses_mask and self.rotation_signs is not None:
+            self.update_quantized_weight_rotated()
+        elif self.uses_mask and not self.uses_rotation and self.channel_mask is not None:
+            self.update_quantized_weight_scaled()
+        elif (self.uses_mask and self.channel_mask is not None) or (self.uses_rotation and self.rotation_signs is not None):
+            raise NotImplementedError(f"{type(self).__name__}: transform is only partly initialised (mask / rotation)")
+        else:
             self.w_quantizer.init_done = True
-            self._requantize(self._transformed_fp_weight(first_pass_done=False))
-
-    def _transformed_fp_weight(self, first_pass_done):
-        w = self.fp_module.weight.data.float()
-        if self.uses_mask and self.channel_mask is not None:
-            w = w / self.channel_mask.reshape(1, -1)
-        return w
+            self._requantize(self.fp_module.weight.data.float())
 
     # ---- activation side ----------------------------------------------------------------------------
     def _act_transform(self):

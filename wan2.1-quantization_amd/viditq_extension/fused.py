@@ -213,6 +213,22 @@ def weight_quant(w, delta, zero_point, qmin, qmax, want_int8=True, want_dequant=
     return q8, dq
 
 
+def weight_export_f16(w, delta_f16, zp_f16):
+    """int8 codes of `w` by the reference's half-precision export equation (quantize_and_save_weight_,
+    ViDiT-Q/examples/Wan2.1/wan/quant_wanx_cuda.py:39-53): clamp(round(f16(w) / delta) - zp, -128, 127)."""
+    rows, cols = _rows_cols("w", w)
+    for n, t in (("delta_f16", delta_f16), ("zp_f16", zp_f16)):
+        _C.check_gpu(n, t)
+        _C.check_dtype(n, t, torch.float16)
+        _C.check_contig(n, t)
+        _C.check_shape(n, t, rows)
+    q8 = torch.empty(w.shape, dtype=torch.int8, device=w.device)
+    with torch.cuda.device(w.device):
+        _C.call("wanq_weight_export_f16", _C.ptr(w), _C.dt(w), _C.ptr(delta_f16), _C.ptr(zp_f16), _C.ptr(q8), rows, cols,
+                _C.stream())
+    return q8
+
+
 # ---- ViDiT activation transform fused with the quantiser (no counterpart in the reference extension: its kernel mode
 #      skips the transform altogether, SURVEY D3; simulation mode does x*mask -> x.double() @ R in torch)
 def _rotation_args(premul, rotation, cols, device):

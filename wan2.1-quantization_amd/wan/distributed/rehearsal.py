@@ -1,0 +1,39 @@
+"""Rehearsal of the multi-rank control flow on a ONE-GPU box.
+
+RCCL refuses two ranks on the same device, so a rehearsal runs its ranks over a gloo process group and stages the three
+collectives `wan.distributed.parallel` uses (all_to_all_single, all_gather_into_tensor, all_gather) through host memory.
+Used by `bench.py` under WANQ_BENCH_REHEARSE_ON_ONE_GPU=1 and by tests/sp_rehearsal_worker.py; never a measurement and
+never on the product path (one process per GPU calls torch.distributed with backend "nccl" = RCCL directly)."""
+import torch
+import torch.distributed as dist
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def stage_collectives_through_host():
+    """Monkey-patch torch.distributed's three collectives with host-staged versions (gloo cannot take device tensors)."""
+    a2a, agt, ag = dist.all_to_all_single, dist.all_gather_into_tensor, dist.all_gather
+
+    def all_to_all_single(output, input, group=None, async_op=False, **kw):
+        o = torch.empty(output.shape, dtype=output.dtype)
+        a2a(o, input.cpu(), group=group)
+        output.copy_(o)
+        return _Done() if async_op else None
+
+    def all_gather_into_tensor(output, input, group=None, async_op=False):
+        o = torch.empty(output.shape, dtype=output.dtype)
+        agt(o, input.cpu(), group=group)
+        output.copy_(o)
+        return _Done() if async_op else None
+
+    def all_gather(tensor_list, tensor, group=None, async_op=False):
+        tmp = [torch.empty(t.shape, dtype=t.dtype) for t in tensor_list]
+        ag(tmp, tensor.cpu(), group=group)
+        for d, s in zip(tensor_list, tmp):
+            d.copy_(s)
+        return _Done() if async_op else None
+
+    dist.all_to_all_single, dist.all_gather_into_tensor, dist.all_gather = all_to_all_single, all_gather_into_tensor, all_gather

@@ -47,23 +47,47 @@ class QuantWanModel(WanModel, QuantModel):
         self.quant_layer_refactor()
 
     # ---- kernel mode -----------------------------------------------------------------------------------
-    def quantize_and_save_weight(self, save_path=None):
+    def quantize_and_save_weight(self, save_path=None, reference_format=False):
         """Integer state dict of every quantized Linear (reference quant_wanx.py:137-185): `<name>.weight` int8,
-        `<name>.scale_weight`, `<name>.zp_weight`, `<name>.bias`; fp_module / fp_weight entries are dropped.
-        Parameters are stored fp32 (the reference casts delta / zero_point to fp16, losing the precision the
-        simulation path has); ViDiT layers also carry `<name>.act_premul` (= channel_mask * rotation signs)."""
+        `<name>.scale_weight`, `<name>.zp_weight`, `<name>.bias`; fp_module / fp_weight entries are dropped; ViDiT /
+        SmoothQuant / QuaRot layers also carry `<name>.act_premul` (= channel_mask * rotation signs).
+
+        reference_format=False (default): parameters fp32 -- the precision the simulation path computes with.
+        reference_format=True: byte-for-byte what the reference's `int_weight.pt` holds, so that its loader
+        (W8A8OF16LinearDynamicInputScale buffers, K/viditq_extension/nn/qlinear.py:23-58) can read it: fp16 `scale_weight`,
+        fp16 `zp_weight` (integer-valued: the loader copies it into an int16 buffer), fp16 bias, every other floating tensor
+        fp16 (the kernel-mode blocks are `.half()`), `blocks.N.norm{1,2}.weight` = ones, and int8 codes by the reference's
+        own half-precision equation (quantize_and_save_weight_, quant_wanx_cuda.py:39-53) on the HIP export kernel.  For a
+        plain QuantizedLinear that equation is applied to the FP weight, exactly as the reference does; for a transformed
+        layer it is applied to the layer's transformed weight (the reference applies it to the RAW weight with parameters
+        fitted on the transformed one -- SURVEY D3 -- and its kernel path has no activation transform to go with it)."""
+        from viditq_extension import fused
+
         sd = {}
         skip = set()
+        f16 = torch.float16
         for name, mod in self.named_modules():
             if isinstance(mod, QuantizedLinear) and mod.w_quantizer is not None and mod.quant_mode:
                 wq = mod.w_quantizer
-                sd[name + ".weight"] = mod.int_weight.clone()
-                sd[name + ".scale_weight"] = wq.delta.reshape(-1).float().clone()
-                if not wq.sym:
-                    sd[name + ".zp_weight"] = wq.zero_point.reshape(-1).float().clone()
-                if mod.bias is not None:
-                    sd[name + ".bias"] = mod.bias.detach().float().clone()
                 premul, _ = mod._act_transform()
+                if reference_format:
+                    if wq.n_bits != 8:
+                        raise NotImplementedError(f"{name}: the reference's int_weight.pt format is W8 only (n_bits={wq.n_bits})")
+                    s16 = wq.delta.reshape(-1).to(f16).contiguous()
+                    z16 = (torch.zeros_like(s16) if wq.sym else wq.zero_point.reshape(-1).to(f16)).contiguous()
+                    src = mod.fp_module.weight.data if premul is None else mod.weight.data
+                    sd[name + ".weight"] = fused.weight_export_f16(src.detach().contiguous(), s16, z16)
+                    sd[name + ".scale_weight"] = s16
+                    sd[name + ".zp_weight"] = z16
+                    if mod.bias is not None:
+                        sd[name + ".bias"] = mod.bias.detach().to(f16).clone()
+                else:
+                    sd[name + ".weight"] = mod.int_weight.clone()
+                    sd[name + ".scale_weight"] = wq.delta.reshape(-1).float().clone()
+                    if not wq.sym:
+                        sd[name + ".zp_weight"] = wq.zero_point.reshape(-1).float().clone()
+                    if mod.bias is not None:
+                        sd[name + ".bias"] = mod.bias.detach().float().clone()
                 if premul is not None:
                     sd[name + ".act_premul"] = premul.clone()
                 skip.add(name)
@@ -71,23 +95,52 @@ class QuantWanModel(WanModel, QuantModel):
             owner = k.rsplit(".", 1)[0]
             if any(owner == s or owner.startswith(s + ".") for s in skip):
                 continue
-            sd[k] = v.detach().clone()
+            v = v.detach().clone()
+            sd[k] = v.to(f16) if reference_format and v.is_floating_point() and k.startswith("blocks.") else v
+        if reference_format:
+            for i in range(len(self.blocks)):  # the fused LayerNorm kernel takes a weight: vanilla LN = ones (quant_wanx.py:173-177)
+                sd[f"blocks.{i}.norm1.weight"] = torch.ones(self.dim, dtype=f16)
+                sd[f"blocks.{i}.norm2.weight"] = torch.ones(self.dim, dtype=f16)
         if save_path:
             torch.save(sd, save_path)
         return sd
 
     def hardware_forward_refactor(self, load_path=None, seq_len=None, act_dtype=torch.bfloat16):
-        """Switch forward() to kernel mode: every block becomes a WanAttentionBlockWithHipKernel built from the
-        block's current layers (reference quant_wanx.py:188-228 loads `int_weight.pt` into freshly constructed
-        blocks; here the quantized layers in memory are the source of truth, `load_path` is accepted for call
-        compatibility and verified against them when given)."""
+        """Switch forward() to kernel mode: every block becomes a WanAttentionBlockWithHipKernel (reference
+        quant_wanx.py:188-228).  The blocks are built from the model's current layers (which fixes which Linears are
+        quantized and which carry a rotation); with `load_path` the integer checkpoint is then LOADED into them, as the
+        reference does with `int_weight.pt`: codes, scales, zero points, biases and activation pre-multipliers of every
+        quantized Linear come from the file (either format of quantize_and_save_weight), a quantized Linear without its keys
+        or with a shape mismatch is an error, and the number of tensors taken is logged."""
         self.hip_blocks = nn.ModuleList([WanAttentionBlockWithHipKernel.from_float(b, None, False, act_dtype) for b in self.blocks])
         if load_path:
             sd = torch.load(load_path, map_location="cpu", weights_only=True)
+            taken = 0
             for i, hb in enumerate(self.hip_blocks):
-                k = f"blocks.{i}.self_attn.q.weight"
-                if k in sd and hb.self_attn.q.quantized:
-                    assert torch.equal(sd[k], hb.self_attn.q.weight.cpu()), f"{load_path} does not match the in-memory model at {k}"
+                for owner, attr, key in [(hb.self_attn, l, f"self_attn.{l}") for l in "qkvo"] + \
+                                        [(hb.cross_attn, l, f"cross_attn.{l}") for l in "qkvo"] + \
+                                        [(hb, "ffn0", "ffn.0"), (hb, "ffn2", "ffn.2")]:
+                    lin = getattr(owner, attr)
+                    if not lin.quantized:
+                        continue
+                    base = f"blocks.{i}.{key}"
+                    for buf, k, required in (("weight", "weight", True), ("scale_weight", "scale_weight", True),
+                                             ("zp_weight", "zp_weight", lin.zp_weight is not None),
+                                             ("bias", "bias", lin.bias is not None),
+                                             ("act_premul", "act_premul", lin.act_premul is not None)):
+                        dst = getattr(lin, buf)
+                        if f"{base}.{k}" not in sd:
+                            if required:
+                                raise KeyError(f"{load_path}: missing {base}.{k}")
+                            continue
+                        if dst is None:
+                            raise KeyError(f"{load_path}: {base}.{k} present but the model's layer has no {buf}")
+                        src = sd[f"{base}.{k}"]
+                        if tuple(src.shape) != tuple(dst.shape) or (buf == "weight" and src.dtype != torch.int8):
+                            raise ValueError(f"{load_path}: {base}.{k} is {tuple(src.shape)} {src.dtype}, expected {tuple(dst.shape)}")
+                        dst.copy_(src.to(dst.dtype))
+                        taken += 1
+            logger.info("loaded %d tensors of the integer checkpoint %s into the kernel-mode blocks", taken, load_path)
         return self
 
     def software_forward(self):
