@@ -192,14 +192,27 @@ int wanq_layernorm_rotate_quant_rows_multi(const void* x, int x_dtype, const voi
                                            int64_t rows, int cols, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * 4-bit weight storage.  packed[r, j] = (q[r,2j] + bias) | (q[r,2j+1] + bias) << 4, bias 8 for signed codes in
+ * 4-bit weights.  Storage: row-major [N, K/2] bytes, K % 32 == 0; each group of 32 consecutive codes takes 16 bytes = 4
+ * dwords (P0a, P1a, P0b, P1b); for a 16-code half e[0..15] (a = codes 0-15, b = codes 16-31 of the group), as unsigned
+ * nibbles u = e + bias:   P0 byte i = u[i] | u[4+i] << 4,   P1 byte i = u[8+i] | u[12+i] << 4   (i = 0..3),
+ * so `P & 0x0f0f0f0f` and `(P >> 4) & 0x0f0f0f0f` are the dwords of an int8 MFMA operand.  bias 8 for signed codes in
  * [-8,7] (qdiff 4-bit asym, base_quantizer.py:32,89-90), bias 0 for unsigned codes 0..15 (QServe convention,
- * ViDiT-Q/kernels/csrc/qgemm/w4a8/w4a8_per_channel_gemm_cuda_qserve.cu:287-299).  cols % 16 == 0.
- * The reference exports a W4A8 GEMM (w4a8_of16_nobias_weight_asym_qserve) but ships neither a packer nor a
- * module that calls it; here W4 is a storage format: codes are expanded to int8 (wanq_unpack_w4) and run on
- * wanq_gemm_w8a8, whose asymmetric epilogue with zp = -zero covers  y = acc*sW*sA - (sW*zW)*sumA. */
+ * ViDiT-Q/kernels/csrc/qgemm/w4a8/w4a8_per_channel_gemm_cuda_qserve.cu:287-299).  The reference exports a W4A8 GEMM
+ * (w4a8_of16_nobias_weight_asym_qserve) but ships neither a packer nor a module that calls it, and its layout is an NVIDIA
+ * ldmatrix interleave; this layout is the CDNA4 counterpart. */
 int wanq_pack_w4(const int8_t* q, uint8_t* packed, int bias, int64_t rows, int cols, void* stream);
 int wanq_unpack_w4(const uint8_t* packed, int8_t* q, int bias, int64_t rows, int cols, void* stream);
+
+/* W4A8 GEMM: as wanq_gemm_w8a8 with `w_packed` = UNSIGNED nibbles u in [0,15] in the layout above (N x K/2 bytes), expanded to
+ * int8 in registers next to the MFMA (the weight panel's HBM / LDS bytes halve):
+ *   acc[m,n] = sum_k a[m,k] * u[n,k];   y = acc*sa[m]*sw[n] (+ asum[m]*zp[n]*sw[n]) (+ bias[n]) ...   (same epilogue flags)
+ * With zp = -zero this is y = acc*sW*sA - (sW*zW)*sumA (w4a8_per_channel_gemm_cuda_qserve.cu:580-587); signed qdiff codes q
+ * stored with bias 8 use zp = zero_point - 8.  K % 32 == 0.
+ * Replaces qgemm.w4a8_of16_nobias_weight_asym_qserve (ViDiT-Q/kernels/csrc/qgemm/w4a8/..._qserve.cu:304-656). */
+int wanq_gemm_w4a8(const int8_t* a, const uint8_t* w_packed, void* out, int out_dtype, const void* sa,
+                   const void* asum, int tok_dtype, const void* sw, const void* bias, int ch_dtype,
+                   const void* zp, int zp_dtype, const float* gate, const void* residual, int epi_flags,
+                   int64_t M, int N, int K, void* stream);
 
 #ifdef __cplusplus
 }

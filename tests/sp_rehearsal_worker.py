@@ -30,9 +30,11 @@ def main():
     from wan.modules.model import WanModel
     from wan.quant_wanx import QuantWanModel
 
+    # default: a small model; WANQ_REHEARSE_DIMS="5120,13824,40,1" = the 14B block dimensions (config 4), one block
+    dim, ffn_dim, heads, layers = (int(v) for v in os.environ.get("WANQ_REHEARSE_DIMS", "512,1024,4,2").split(","))
     torch.manual_seed(0)
     with torch.device(dev):
-        fp = WanModel(dim=512, ffn_dim=1024, num_heads=4, num_layers=2, text_dim=64, freq_dim=64).eval()
+        fp = WanModel(dim=dim, ffn_dim=ffn_dim, num_heads=heads, num_layers=layers, text_dim=64, freq_dim=64).eval()
     g = torch.Generator(device=dev).manual_seed(1)
     for m in fp.modules():
         if isinstance(m, torch.nn.Linear) and m.bias is not None:
@@ -68,12 +70,19 @@ def main():
     # ---- Ulysses over both ranks (cfg 1 x sp 2), with the head-chunked exchange pipeline forced on (2 local heads -> 1 + 1)
     import wan.quant_wanx_hip as qh
     qh._FORCE_CHUNK_UNIT = 1
-    assert len(qh._head_chunks(2, 270, dev)) == 2
+    assert len(qh._head_chunks(heads // world, 270, dev)) >= 2
     plan = ParallelPlan(world, rank, 1, world)
     assert plan.sp.size == world
     sl = seq_len_for(shape, sp_size=world)
     out = model([latent], t, [ctx_c], sl, plan.sp)[0]
     e_sp = rel(out, ref_c)
+    if os.environ.get("WANQ_REHEARSE_NO_CFG_PARALLEL") == "1":  # config 4 runs pure Ulysses (bench.py --no-cfg-parallel)
+        torch.cuda.synchronize()
+        print(f"RANK {rank} sp_rel={e_sp:.3e} cfg_rel=skipped finite={bool(torch.isfinite(out).all())}", flush=True)
+        assert e_sp == 0.0, e_sp
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     # ---- CFG parallel (cfg 2 x sp 1): each rank runs one of the two passes
     plan2 = ParallelPlan(world, rank, 2, 1)
     mine = model([latent], t, [ctx_c if plan2.cfg_index == 0 else ctx_u], seq_len_for(shape), plan2.sp)[0]

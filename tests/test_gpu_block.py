@@ -228,3 +228,84 @@ def test_kernel_mode_block_with_vidit_and_fp_layers_vs_oracle():
     err = rel_err(out.float().cpu(), ref)
     print(f"shipped-config block (ViDiT q/k/v + FP rest): rel err vs oracle {err:.2e}")
     assert err < 1e-2
+
+
+def test_config5_w4a8_mixed_block_14b_shapes_and_checkpoint_roundtrip(tmp_path):
+    """BASELINE config 5 on one 14B-shape block (dim 5120, ffn 13824, 40 heads): quant_configs/w4a8_mixed.yaml ->
+    quant_layer_refactor + bitwidth_refactor (FFN weights 4 bit, the rest 8; Q/base/quant_model.py:76-105,
+    mixed_precision_quantizer.py:56-186) -> kernel-mode block with the 4-bit weights PACKED in HBM and expanded inside the
+    GEMM, vs the simulation oracle with 4-bit FFN fake-quant weights.  Then the integer checkpoint round trip: packed uint8
+    [N, K/2] on disk, loaded back by hardware_forward_refactor into a second model, bit-equal output."""
+    import os
+
+    from qdiff import config as qcfg
+    from qdiff.base.quant_layer import QuantizedLinear
+    from wan import ops
+    from wan.modules.model import WanModel
+    from wan.quant_wanx import QuantWanModel
+    from wan.quant_wanx_hip import _FpSrc
+
+    dim, ffn, heads, grid, lc = 5120, 13824, 40, (1, 6, 8), 32
+    cfgp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "wan2.1-quantization_amd", "quant_configs", "w4a8_mixed.yaml")
+    quant_config = qcfg.load(cfgp)
+    torch.manual_seed(0)
+    with torch.device(DEV):
+        fp = WanModel(dim=dim, ffn_dim=ffn, num_heads=heads, num_layers=1, text_dim=64, freq_dim=64).eval()
+    blk = make_block(dim, ffn, heads, 0)
+    fp.blocks[0].load_state_dict(blk.state_dict())
+    sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    model = QuantWanModel.from_float(fp, quant_config)
+    model.quant_layer_refactor()
+    model.bitwidth_refactor()
+    model.set_init_done()
+    b0 = model.blocks[0]
+    assert b0.ffn[0].w_quantizer.n_bits == 4 and b0.ffn[2].w_quantizer.n_bits == 4 and b0.self_attn.q.w_quantizer.n_bits == 8
+    assert b0.ffn[0]._codes.dtype == torch.uint8 and tuple(b0.ffn[0]._codes.shape) == (ffn, dim // 2)  # packed in the model
+    model.hardware_forward_refactor()
+    hb = model.hip_blocks[0]
+    assert hb.ffn0.w_bits == 4 and hb.ffn0.weight.dtype == torch.uint8 and hb.ffn2.weight.shape == (dim, ffn // 2)
+    assert hb.self_attn.q.w_bits == 8
+
+    n_tok = grid[0] * grid[1] * grid[2]
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n_tok, dim, generator=g)
+    x[:, 5] *= 12.0
+    e0 = torch.randn(1, 6, dim, generator=g) * 0.3
+    ctx = torch.randn(lc, dim, generator=g)
+    freqs = wr.rope_freqs(dim // heads)
+    lin = {}
+    for nm in wr.LINEARS:
+        lin[nm] = wr.FakeQuantLinear(sd[nm + ".weight"], sd[nm + ".bias"], 4 if nm.startswith("ffn") else 8, 8, False)
+    norm_w = {k: sd[k + ".weight"].float() for k in ("self_attn.norm_q", "self_attn.norm_k", "cross_attn.norm_q", "cross_attn.norm_k")}
+    ref = wr.BlockRef(lin, norm_w, sd["modulation"], heads, 1e-6, (sd["norm3.weight"].float(), sd["norm3.bias"].float()))(x, e0, grid, n_tok, ctx, freqs)
+    ref8 = wr.block_from_state(sd, heads, quant=True)(x, e0, grid, n_tok, ctx, freqs)
+    rope = ops.rope_table(freqs, grid, DEV)
+    out = hb(x.to(DEV).clone(), e0.to(DEV), rope, n_tok, _FpSrc(ctx.to(DEV), torch.bfloat16)).float().cpu()
+    err = rel_err(out, ref)
+    print(f"config-5 block (W4 FFN, W8 rest): rel err vs 4-bit oracle {err:.2e}; 4-bit vs 8-bit oracle {rel_err(ref, ref8):.2e}")
+    assert err < 1.5e-2 and err < 0.5 * rel_err(ref, ref8) + 5e-3
+
+    # ---- on-disk artefact: packed codes, loaded into a fresh model's kernel-mode blocks
+    path = str(tmp_path / "int_weight.pt")
+    sdw = model.quantize_and_save_weight(path)
+    assert sdw["blocks.0.ffn.0.weight"].dtype == torch.uint8 and tuple(sdw["blocks.0.ffn.0.weight"].shape) == (ffn, dim // 2)
+    assert sdw["blocks.0.self_attn.q.weight"].dtype == torch.int8
+    model2 = QuantWanModel.from_float(fp, quant_config)
+    model2.quant_layer_refactor()
+    model2.bitwidth_refactor()
+    model2.set_init_done()
+    model2.hardware_forward_refactor()
+    model2.hardware_forward_refactor(path)
+    out2 = model2.hip_blocks[0](x.to(DEV).clone(), e0.to(DEV), rope, n_tok, _FpSrc(ctx.to(DEV), torch.bfloat16)).float().cpu()
+    assert torch.equal(out2, out)
+    # the file, not the in-memory layers, is what the kernel-mode blocks hold afterwards
+    tampered = dict(sdw)
+    tampered["blocks.0.ffn.2.scale_weight"] = sdw["blocks.0.ffn.2.scale_weight"] * 2
+    torch.save(tampered, path)
+    model2.hardware_forward_refactor(path)
+    out3 = model2.hip_blocks[0](x.to(DEV).clone(), e0.to(DEV), rope, n_tok, _FpSrc(ctx.to(DEV), torch.bfloat16)).float().cpu()
+    assert not torch.equal(out3, out)
+    with pytest.raises(KeyError):
+        bad = {k: v for k, v in sdw.items() if k != "blocks.0.cross_attn.o.scale_weight"}
+        torch.save(bad, path)
+        model2.hardware_forward_refactor(path)

@@ -90,3 +90,67 @@ def test_attention_full_size_properties_and_sampled_queries():
     got = o[rows].float()
     assert float((got - ref).abs().max()) < 3e-2
     assert float((got - ref).norm() / ref.norm()) < 1e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 4 / 5: Wan2.1-T2V-14B at 1280x720x81f under Ulysses = 8.  One rank holds 75600 / 8 = 9450 tokens (a ragged
+# count: 36 full 256-row tiles + 234 rows), C = 5120, F = 13824, and attends with its 40 / 8 = 5 heads over all 75600 keys.
+LR, C14, F14, HR, LK14 = 9450, 5120, 13824, 5, 75600
+
+
+@pytest.mark.parametrize("N,K,w4", [(C14, C14, False), (F14, C14, False), (C14, F14, False), (F14, C14, True), (C14, F14, True)])
+def test_config4_per_rank_gemm_checksums_and_sampled_rows(N, K, w4):
+    import viditq_extension.qgemm as qgemm
+
+    a = _rand_i8((LR, K), 11)
+    if w4:
+        g = torch.Generator(device=DEV).manual_seed(12)
+        w = torch.randint(0, 16, (N, K), dtype=torch.int8, device=DEV, generator=g)
+        acc = qgemm.w4a8_o32(a, qgemm.pack_w4(w, bias=0))
+    else:
+        w = _rand_i8((N, K), 12)
+        acc = qgemm.w8a8_o32(a, w)
+    assert acc.shape == (LR, N) and acc.dtype == torch.int32
+    a64, w64 = a.double(), w.double()
+    np.testing.assert_array_equal(acc.double().sum(1).cpu().numpy(), (a64 @ w64.sum(0)).cpu().numpy())
+    np.testing.assert_array_equal(acc.double().sum(0).cpu().numpy(), (w64 @ a64.sum(0)).cpu().numpy())
+    rows = np.unique(np.concatenate([np.random.default_rng(4).integers(0, LR, 40), [0, 255, 256, 9215, 9216, LR - 1]]))
+    np.testing.assert_array_equal(acc[rows].cpu().numpy(), kr.w8a8_o32(a[rows].cpu().numpy(), w.cpu().numpy()))
+
+
+def test_config4_per_rank_quantize_13824_columns():
+    import viditq_extension.fused as fused
+
+    g = torch.Generator(device=DEV).manual_seed(13)
+    x = (torch.randn(LR, F14, device=DEV, generator=g) * torch.exp(torch.randn(F14, device=DEV, generator=g))).to(torch.bfloat16)
+    scale, ssum = torch.zeros(LR, device=DEV), torch.zeros(LR, device=DEV)
+    q = fused.quant_sum(x, ssum, scale)
+    amax = x.float().abs().amax(1)
+    assert torch.equal(scale, torch.maximum(amax / torch.full_like(amax, 127.0), torch.full_like(amax, 1e-6)))
+    assert bool((q.int().abs().amax(1) == 127).all())
+    rows = np.unique(np.concatenate([np.random.default_rng(5).integers(0, LR, 24), [0, LR - 1]]))
+    oq, oscale, _ = kr.quant_sum(x[rows].float().cpu().numpy())
+    np.testing.assert_array_equal(q[rows].cpu().numpy(), oq)
+    np.testing.assert_array_equal(scale[rows].cpu().numpy(), oscale)
+
+
+def test_config4_per_rank_attention_5_heads_75600_keys():
+    """The Ulysses-8 attention call of one rank: all 75600 queries and keys of its 5 heads (split-KV chosen by the library's own
+    policy), sampled queries against the fp32 definition and the partition-of-unity property over the whole output."""
+    from wan import ops
+
+    g = torch.Generator(device=DEV).manual_seed(6)
+    q = torch.randn(LK14, HR * 128, device=DEV, generator=g).to(torch.bfloat16)
+    k = torch.randn(LK14, HR * 128, device=DEV, generator=g).to(torch.bfloat16)
+    v = torch.randn(LK14, HR * 128, device=DEV, generator=g).to(torch.bfloat16)
+    o = ops.attention(q, k, v, HR)
+    assert bool(torch.isfinite(o.float()).all())
+    vc = torch.randn(1, HR * 128, device=DEV, generator=g).to(torch.bfloat16).expand(LK14, -1).contiguous()
+    oc = ops.attention(q, k, vc, HR).float()
+    assert float((oc - vc.float()).abs().max()) <= 2.0 ** -7 * float(vc.float().abs().max())
+    rows = torch.from_numpy(np.unique(np.concatenate([np.random.default_rng(7).integers(0, LK14, 40), [0, 255, LK14 - 1]]))).to(DEV)
+    qs = q[rows].float().view(-1, HR, 128).transpose(0, 1)
+    kk, vv = k.float().view(LK14, HR, 128).transpose(0, 1), v.float().view(LK14, HR, 128).transpose(0, 1)
+    ref = (torch.softmax(qs @ kk.transpose(1, 2) / 128 ** 0.5, dim=-1) @ vv).transpose(0, 1).reshape(len(rows), HR * 128)
+    got = o[rows].float()
+    assert float((got - ref).abs().max()) < 3e-2 and float((got - ref).norm() / ref.norm()) < 1e-2

@@ -133,6 +133,16 @@ def test_shape_errors_raise_runtime_error():
         qgemm().w8a8_o32(torch.zeros(8, 32, dtype=torch.int8, device=DEV), w)
 
 
+def _pack_w4_ref(q, bias):
+    """The library's packed layout restated in numpy (include/wanq_hip.h): per 32 codes 16 bytes = (P0a, P1a, P0b, P1b);
+    for a 16-code half e: P0 byte i = u[i] | u[4+i] << 4, P1 byte i = u[8+i] | u[12+i] << 4, u = e + bias."""
+    N, K = q.shape
+    u = (q.astype(np.int32) + bias).reshape(N, K // 16, 16)
+    p0 = u[:, :, 0:4] | (u[:, :, 4:8] << 4)
+    p1 = u[:, :, 8:12] | (u[:, :, 12:16] << 4)
+    return np.concatenate([p0, p1], axis=2).reshape(N, K // 2).astype(np.uint8)
+
+
 def test_w4_pack_unpack_roundtrip_and_w4a8_equation():
     """4-bit codes survive pack/unpack exactly; the QServe W4A8 entry point reproduces its equation
     (oracle/kernel_ref.py::w4a8_of16, K/csrc/qgemm/w4a8/w4a8_per_channel_gemm_cuda_qserve.cu:580-587)."""
@@ -141,11 +151,11 @@ def test_w4_pack_unpack_roundtrip_and_w4a8_equation():
     q = rng.integers(-8, 8, size=(N, K), dtype=np.int8)
     packed = qgemm().pack_w4(t(q), bias=8)
     assert packed.shape == (N, K // 2) and packed.dtype == torch.uint8
-    ref = ((q[:, 0::2].astype(np.int32) + 8) | ((q[:, 1::2].astype(np.int32) + 8) << 4)).astype(np.uint8)
-    assert np.array_equal(packed.cpu().numpy(), ref)
+    assert np.array_equal(packed.cpu().numpy(), _pack_w4_ref(q, 8))
     assert np.array_equal(qgemm().unpack_w4(packed, bias=8).cpu().numpy(), q)
 
     u4 = rng.integers(0, 16, size=(N, K), dtype=np.int8)
+    assert np.array_equal(qgemm().pack_w4(t(u4), bias=0).cpu().numpy(), _pack_w4_ref(u4, 0))
     a = rng.integers(-127, 128, size=(M, K), dtype=np.int8)
     ws = rng.uniform(0.01, 0.03, N).astype(np.float16)
     zw = rng.integers(0, 16, N).astype(np.float32)
@@ -156,3 +166,37 @@ def test_w4_pack_unpack_roundtrip_and_w4a8_equation():
     qgemm().w4a8_of16_nobias_weight_asym_qserve(t(a), qgemm().pack_w4(t(u4), bias=0), t(ws), t(asc), t(w_sz), t(a_ssum), out)
     refy = kr.w4a8_of16(a, u4, ws, asc, w_sz, a_ssum)
     np.testing.assert_allclose(out.float().cpu().numpy(), refy, rtol=4e-3, atol=4e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(77, 136, 256), (130, 128, 32), (512, 256, 128), (1000, 520, 1536), (2048, 1536, 8960),
+                                   (700, 264, 13824), (300, 5120, 13824)])
+def test_w4a8_accumulators_bit_exact(M, N, K):
+    """int8 activations x packed 4-bit weights, nibbles expanded in registers (both kernels: 128x128 for small / ragged
+    shapes, persistent 256x256 from M = 512): int32 accumulators == the integer product on the unpacked codes, exactly."""
+    rng = np.random.default_rng(M + N + K)
+    a = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+    u4 = rng.integers(0, 16, size=(N, K), dtype=np.int8)
+    if K == 13824:  # extreme values: |acc| up to 13824 * 128 * 15 = 2.65e7, still exact in int32
+        a[:2] = -128
+        u4[:3] = 15
+    acc = qgemm().w4a8_o32(t(a), qgemm().pack_w4(t(u4), bias=0))
+    assert np.array_equal(acc.cpu().numpy(), kr.w8a8_o32(a, u4))
+
+
+def test_w4a8_epilogue_matches_w8a8_on_unpacked_codes():
+    """Same epilogue as the W8 kernel (gelu / gate + residual / bias), signed codes stored with bias 8 and zp - 8."""
+    rng = np.random.default_rng(9)
+    M, N, K = 777, 384, 512
+    a = t(rng.integers(-127, 128, size=(M, K), dtype=np.int8))
+    q = rng.integers(-8, 8, size=(N, K), dtype=np.int8)
+    sa, sw = t(rng.uniform(0.005, 0.02, M).astype(np.float32)), t(rng.uniform(0.01, 0.03, N).astype(np.float32))
+    asum = (a.float().sum(1) * sa).contiguous()
+    zp = t(rng.integers(0, 16, N).astype(np.float32))
+    bias = t(rng.normal(size=N).astype(np.float32))
+    gate, res = t(rng.normal(size=N).astype(np.float32)), t(rng.normal(size=(M, N)).astype(np.float32))
+    packed = qgemm().pack_w4(t(q), bias=8)
+    for kw in (dict(out_dtype=torch.bfloat16, gelu=True), dict(out_dtype=torch.float32, gate=gate, residual=res),
+               dict(out_dtype=torch.float16)):
+        y8 = qgemm().w8a8_linear(a, t(q), sa, sw, bias, asum, zp, **kw)
+        y4 = qgemm().w8a8_linear(a, packed, sa, sw, bias, asum, zp - 8.0, w4=True, **kw)
+        assert torch.allclose(y4.float(), y8.float(), rtol=2e-3, atol=2e-3), (y4.float() - y8.float()).abs().max()

@@ -26,6 +26,17 @@ def test_two_ranks_on_one_gpu_match_single_rank():
     assert r.stdout.count("sp_rel=") == 2, r.stdout[-2000:]
 
 
+def test_two_ranks_ulysses_at_14b_block_dims():
+    """Config 4's block dimensions (dim 5120, ffn 13824, 40 heads -> 20 per rank, head-chunked exchange) under pure Ulysses,
+    two ranks on the one GPU: bit-equal to the single-rank output."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(HERE, "sp_rehearsal_worker.py")]
+    env = dict(os.environ, OMP_NUM_THREADS="4", WANQ_REHEARSE_DIMS="5120,13824,40,1", WANQ_REHEARSE_NO_CFG_PARALLEL="1")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, f"14B-dims rehearsal failed:\n{r.stdout[-4000:]}\n{r.stderr[-4000:]}"
+    assert r.stdout.count("sp_rel=0.000e+00") == 2, r.stdout[-2000:]
+
+
 def test_bench_multi_rank_control_flow_rehearsal():
     """bench.py --gpus 2 end to end (cfg-A frame count so that it takes seconds): rendezvous, parallel plan, calibration on
     every rank, timed step with the cfg all-gather, max-over-ranks timing, one JSON line from rank 0."""

@@ -126,7 +126,9 @@ struct OutIo<WANQ_F32> {
   }
 };
 
-template <int OUT>
+// W4: `w` holds 4-bit codes in the packed layout of wanq_pack_w4 (bias 0 nibbles, K/2 bytes per row); the staging pass expands
+// a thread's 8 packed bytes to the 16 int8 of its chunk, so LDS and the main loop are those of the W8 form.
+template <int OUT, bool W4>
 __global__ __launch_bounds__(256, 2) void gemm_w8a8_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void gemm_w8a8_kernel(const GemmParams p) {
     const int gm = (m0 + row < p.M) ? (m0 + row) : (p.M - 1);
     const int gn = (n0 + row < p.N) ? (n0 + row) : (p.N - 1);
     ga[i] = p.a + (int64_t)gm * K + c * 16;
-    gw[i] = p.w + (int64_t)gn * K + c * 16;
+    gw[i] = W4 ? p.w + (int64_t)gn * (K / 2) + c * 8 : p.w + (int64_t)gn * K + c * 16;
     soff[i] = lds_off(row, c);
     kc[i] = c * 16;
   }
@@ -170,7 +172,12 @@ __global__ __launch_bounds__(256, 2) void gemm_w8a8_kernel(const GemmParams p) {
     for (int i = 0; i < 4; ++i) {
       if (kb + kc[i] < K) {
         ra[i] = *reinterpret_cast<const uint4*>(ga[i] + kb);
-        rw[i] = *reinterpret_cast<const uint4*>(gw[i] + kb);
+        if (W4) {
+          const uint2 t = *reinterpret_cast<const uint2*>(gw[i] + kb / 2);
+          rw[i] = make_uint4(t.x & 0x0f0f0f0fu, (t.x >> 4) & 0x0f0f0f0fu, t.y & 0x0f0f0f0fu, (t.y >> 4) & 0x0f0f0f0fu);
+        } else {
+          rw[i] = *reinterpret_cast<const uint4*>(gw[i] + kb);
+        }
       } else {
         ra[i] = make_uint4(0, 0, 0, 0);
         rw[i] = make_uint4(0, 0, 0, 0);
@@ -293,7 +300,14 @@ __global__ __launch_bounds__(256, 2) void gemm_w8a8_kernel(const GemmParams p) {
 constexpr int B2M = 256, B2N = 256, B2K = 128;
 constexpr int B2_STAGE = (B2M + B2N) * B2K;  // 64 KiB
 
-template <int OUT>
+// W4 (packed 4-bit weights, wanq_pack_w4 layout): a K-tile of the weight panel is 256 rows x 64 B = 16 KiB instead of 32 (two
+// LDS-DMA instructions per wave instead of four: the weight half of the ingest stream -- the loop's limiter -- halves); a lane
+// reads 16 packed bytes = 32 codes with ONE ds_read_b128 and expands them in registers (and / shift+and) into the MFMA operands
+// of two k-steps.  The k order inside a K-tile is therefore: k-step 2t+u, lane half fh <-> 16-byte activation chunk
+// 4t + 2fh + u (any bijection works as long as both operands use it).  LDS image of the packed panel: 64-B rows, 16-B pieces
+// XORed with (row>>2)&3 (conflict-free for the b128 lane groups, and a whole 16-B piece moves, so the DMA source stays 16 B
+// contiguous).
+template <int OUT, bool W4>
 __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void lds_void;
@@ -329,19 +343,27 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
       const int row = drow + 64 * g;
       const int lc = (lane & 7) ^ ((row >> 1) & 7);  // logical chunk that belongs at this physical slot
       const int gm = (m0 + row < p.M) ? (m0 + row) : (p.M - 1);
-      const int gn = (n0 + row < p.N) ? (n0 + row) : (p.N - 1);
       srcx[g] = (uint32_t)gm * (uint32_t)K + lc * 16;
-      srcw[g] = (uint32_t)gn * (uint32_t)K + lc * 16;
+      if (!W4) {
+        const int gn = (n0 + row < p.N) ? (n0 + row) : (p.N - 1);
+        srcw[g] = (uint32_t)gn * (uint32_t)K + lc * 16;
+      } else if (g < 2) {  // instruction g fills packed rows 16*(wave + 8g) .. +15: 4 lanes (16-B pieces) per 64-B row
+        const int rw_ = 16 * (wave + 8 * g) + (lane >> 2);
+        const int lp = (lane & 3) ^ ((rw_ >> 2) & 3);
+        const int gn = (n0 + rw_ < p.N) ? (n0 + rw_) : (p.N - 1);
+        srcw[g] = (uint32_t)gn * (uint32_t)(K / 2) + lp * 16;
+      }
     }
   };
 #define B2_ISSUE(kt, stage)                                                                              \
   do {                                                                                                   \
     char* sx_ = smem + (stage) * B2_STAGE + wave * 1024;                                                 \
     const int8_t* ak_ = p.a + (kt) * B2K;                                                                \
-    const int8_t* wk_ = p.w + (kt) * B2K;                                                                \
+    const int8_t* wk_ = p.w + (kt) * (W4 ? B2K / 2 : B2K);                                               \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                      \
       __builtin_amdgcn_global_load_lds((glb_void*)(ak_ + srcx[g]), (lds_void*)(sx_ + g * 8192), 16, 0, 0); \
-      __builtin_amdgcn_global_load_lds((glb_void*)(wk_ + srcw[g]), (lds_void*)(sx_ + B2M * B2K + g * 8192), 16, 0, 0); \
+      if (!W4 || g < 2)                                                                                  \
+        __builtin_amdgcn_global_load_lds((glb_void*)(wk_ + srcw[g]), (lds_void*)(sx_ + B2M * B2K + g * 8192), 16, 0, 0); \
     }                                                                                                    \
   } while (0)
 
@@ -350,8 +372,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
   const int fsw = (fr >> 1) & 7;
   int ck[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) ck[ks] = ((2 * ks + fh) ^ fsw) << 4;
-  const int rowx = (wm * 128 + fr) * B2K, roww = B2M * B2K + (wn * 64 + fr) * B2K;
+  for (int ks = 0; ks < 4; ++ks) ck[ks] = (((W4 ? 4 * (ks >> 1) + 2 * fh + (ks & 1) : 2 * ks + fh)) ^ fsw) << 4;
+  const int rowx = (wm * 128 + fr) * B2K;
+  const int roww = B2M * B2K + (wn * 64 + fr) * (W4 ? B2K / 2 : B2K);
+  const int cq0 = ((0 + fh) ^ ((fr >> 2) & 3)) << 4, cq1 = ((2 + fh) ^ ((fr >> 2) & 3)) << 4;  // W4: packed piece of t = 0, 1
 
   int tile = blockIdx.x;
   if (tile >= ntiles) return;
@@ -382,26 +406,64 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
       __builtin_amdgcn_sched_barrier(0);
       if (kt + 1 < nk) B2_ISSUE(kt + 1, (kt + 1) & 1);
       const char* st = smem + (kt & 1) * B2_STAGE;
-      v4i wf[2][2], xf[2][4];
+      v4i xf[2][4];
+      if (!W4) {
+        v4i wf[2][2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) wf[0][i] = *reinterpret_cast<const v4i*>(st + roww + ck[0] + i * 32 * B2K);
+        for (int i = 0; i < 2; ++i) wf[0][i] = *reinterpret_cast<const v4i*>(st + roww + ck[0] + i * 32 * B2K);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xf[0][j] = *reinterpret_cast<const v4i*>(st + rowx + ck[0] + j * 32 * B2K);
+        for (int j = 0; j < 4; ++j) xf[0][j] = *reinterpret_cast<const v4i*>(st + rowx + ck[0] + j * 32 * B2K);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int cb = ks & 1, nb = cb ^ 1;
-        if (ks < 3) {
+        for (int ks = 0; ks < 4; ++ks) {
+          const int cb = ks & 1, nb = cb ^ 1;
+          if (ks < 3) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i) wf[nb][i] = *reinterpret_cast<const v4i*>(st + roww + ck[ks + 1] + i * 32 * B2K);
+            for (int i = 0; i < 2; ++i) wf[nb][i] = *reinterpret_cast<const v4i*>(st + roww + ck[ks + 1] + i * 32 * B2K);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) xf[nb][j] = *reinterpret_cast<const v4i*>(st + rowx + ck[ks + 1] + j * 32 * B2K);
+            for (int j = 0; j < 4; ++j) xf[nb][j] = *reinterpret_cast<const v4i*>(st + rowx + ck[ks + 1] + j * 32 * B2K);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // keep the reads of k-step s+1 AHEAD of the MFMAs of k-step s
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[cb][i], xf[cb][j], acc[i][j], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);  // keep the reads of k-step s+1 AHEAD of the MFMAs of k-step s
+      } else {
+        // wq[i]: 32 packed codes of weight row block i; wa / wb[t][i]: the int8 operands of k-steps 2t and 2t+1
+        v4i wq[2], wa[2][2], wb[2][2];
+        const v4i m4 = {0x0f0f0f0f, 0x0f0f0f0f, 0x0f0f0f0f, 0x0f0f0f0f};
+#define B2_UNPACK(t)                                                                        \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                           \
+    const v4i lo_ = wq[i] & m4, hi_ = (wq[i] >> 4) & m4;                                    \
+    wa[t][i] = v4i{lo_[0], hi_[0], lo_[1], hi_[1]};                                         \
+    wb[t][i] = v4i{lo_[2], hi_[2], lo_[3], hi_[3]};                                         \
+  }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) wq[i] = *reinterpret_cast<const v4i*>(st + roww + cq0 + i * 32 * (B2K / 2));
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[cb][i], xf[cb][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) xf[0][j] = *reinterpret_cast<const v4i*>(st + rowx + ck[0] + j * 32 * B2K);
+        B2_UNPACK(0)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int cb = ks & 1, nb = cb ^ 1;
+          if (ks < 3) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xf[nb][j] = *reinterpret_cast<const v4i*>(st + rowx + ck[ks + 1] + j * 32 * B2K);
+          }
+          if (ks == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wq[i] = *reinterpret_cast<const v4i*>(st + roww + cq1 + i * 32 * (B2K / 2));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8((ks & 1) ? wb[ks >> 1][i] : wa[ks >> 1][i], xf[cb][j], acc[i][j], 0, 0, 0);
+          if (ks == 1) { B2_UNPACK(1) }
+        }
+#undef B2_UNPACK
       }
     }
 
@@ -580,26 +642,78 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
 #undef B2_ISSUE
 }
 
-template <int OUT>
+template <int OUT, bool W4>
 static int launch_gemm(GemmParams p, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w8a8_kernel<OUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  // function-local static with an initialiser: set once, thread-safe (C++11)
+  static const bool attr_set = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w8a8_kernel<OUT, W4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w8a8_big_kernel<OUT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w8a8_big_kernel<OUT, W4>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * B2_STAGE);
-    attr_set = true;
-  }
+    return true;
+  }();
+  (void)attr_set;
   if (p.M >= 512 && p.K % B2K == 0 && !g_force_v1 && (int64_t)p.M * p.K < (1ll << 32) && (int64_t)p.N * p.K < (1ll << 32)) {
     p.mt = (p.M + B2M - 1) / B2M;
     p.nt = (p.N + B2N - 1) / B2N;
     const int tiles = p.mt * p.nt;
     const int grid = tiles < 256 ? ((tiles + 7) & ~7) : 256;  // one workgroup per CU; % 8 == 0 for the XCD ranges
-    hipLaunchKernelGGL(gemm_w8a8_big_kernel<OUT>, dim3((unsigned)grid), dim3(512), 2 * B2_STAGE, st, p);
+    hipLaunchKernelGGL((gemm_w8a8_big_kernel<OUT, W4>), dim3((unsigned)grid), dim3(512), 2 * B2_STAGE, st, p);
   } else {
-    hipLaunchKernelGGL(gemm_w8a8_kernel<OUT>, dim3((unsigned)(p.mt * p.nt)), dim3(256), 2 * STAGE_BYTES, st, p);
+    hipLaunchKernelGGL((gemm_w8a8_kernel<OUT, W4>), dim3((unsigned)(p.mt * p.nt)), dim3(256), 2 * STAGE_BYTES, st, p);
   }
-  return check_launch("wanq_gemm_w8a8");
+  return check_launch(W4 ? "wanq_gemm_w4a8" : "wanq_gemm_w8a8");
+}
+
+static int gemm_entry(bool w4, const int8_t* a, const void* w, void* out, int out_dtype, const void* sa, const void* asum,
+                      int tok_dtype, const void* sw, const void* bias, int ch_dtype, const void* zp, int zp_dtype,
+                      const float* gate, const void* residual, int epi_flags, int64_t M, int N, int K, void* stream) {
+  const char* what = w4 ? "wanq_gemm_w4a8" : "wanq_gemm_w8a8";
+  WANQ_REQUIRE(a && w && out, WANQ_E_ARG, "%s: a, w and out must be non-NULL", what);
+  WANQ_REQUIRE(out_dtype == WANQ_F16 || out_dtype == WANQ_BF16 || out_dtype == WANQ_F32 || out_dtype == WANQ_I32,
+               WANQ_E_ARG, "%s: bad out dtype %d", what, out_dtype);
+  WANQ_REQUIRE(M >= 0 && M < (1ll << 31) / 2, WANQ_E_SHAPE, "%s: M=%lld out of range", what, (long long)M);
+  WANQ_REQUIRE(N >= 8 && N % 8 == 0, WANQ_E_SHAPE, "%s: N=%d must be a positive multiple of 8", what, N);
+  if (w4) WANQ_REQUIRE(K >= 32 && K % 32 == 0, WANQ_E_SHAPE, "%s: K=%d must be a positive multiple of 32 (packed 4-bit groups)", what, K);
+  else WANQ_REQUIRE(K >= 16 && K % 16 == 0, WANQ_E_SHAPE, "%s: K=%d must be a positive multiple of 16", what, K);
+  if (out_dtype != WANQ_I32) {
+    WANQ_REQUIRE(sa && sw, WANQ_E_ARG, "%s: sa and sw are required for a floating output", what);
+    WANQ_REQUIRE(is_vec(tok_dtype) && is_vec(ch_dtype), WANQ_E_ARG, "%s: tok/ch dtype must be F16 or F32", what);
+    WANQ_REQUIRE(!zp || (asum && (zp_dtype == WANQ_I16 || zp_dtype == WANQ_F32)), WANQ_E_ARG,
+                 "%s: zp needs asum and dtype I16 or F32", what);
+    WANQ_REQUIRE(!(epi_flags & WANQ_EPI_GATE_RES) || (gate && residual), WANQ_E_ARG, "%s: WANQ_EPI_GATE_RES needs gate and residual", what);
+  } else {
+    WANQ_REQUIRE(epi_flags == 0, WANQ_E_ARG, "%s: int32 output takes no epilogue flags", what);
+  }
+  WANQ_REQUIRE((epi_flags & ~(WANQ_EPI_GELU | WANQ_EPI_GATE_RES)) == 0, WANQ_E_ARG, "%s: unknown epilogue flag", what);
+  if (M == 0) return WANQ_OK;
+  {
+    static const bool v1 = [] { const char* e = getenv("WANQ_GEMM_V1"); return e && e[0] == '1'; }();
+    g_force_v1 = v1;
+  }
+  static const int group_m = [] { const char* e = getenv("WANQ_GEMM_GROUP_M"); const int v = e ? atoi(e) : 0; return v > 0 ? v : GROUP_M; }();
+  GemmParams p{};
+  p.a = a; p.w = static_cast<const int8_t*>(w); p.out = out; p.sa = sa; p.asum = asum; p.sw = sw; p.bias = bias; p.zp = zp; p.gate = gate;
+  p.residual = residual; p.tok_dtype = tok_dtype; p.ch_dtype = ch_dtype; p.zp_dtype = zp_dtype; p.epi = epi_flags;
+  p.M = (int)M; p.N = N; p.K = K; p.group_m = group_m;
+  p.mt = (int)((M + BM - 1) / BM);
+  p.nt = (N + BN - 1) / BN;
+  WANQ_REQUIRE((int64_t)p.mt * p.nt < (1ll << 31), WANQ_E_SHAPE, "%s: too many tiles", what);
+  hipStream_t st = (hipStream_t)stream;
+  if (w4) {
+    switch (out_dtype) {
+      case WANQ_F16: return launch_gemm<WANQ_F16, true>(p, st);
+      case WANQ_BF16: return launch_gemm<WANQ_BF16, true>(p, st);
+      case WANQ_F32: return launch_gemm<WANQ_F32, true>(p, st);
+      default: return launch_gemm<WANQ_I32, true>(p, st);
+    }
+  }
+  switch (out_dtype) {
+    case WANQ_F16: return launch_gemm<WANQ_F16, false>(p, st);
+    case WANQ_BF16: return launch_gemm<WANQ_BF16, false>(p, st);
+    case WANQ_F32: return launch_gemm<WANQ_F32, false>(p, st);
+    default: return launch_gemm<WANQ_I32, false>(p, st);
+  }
 }
 
 }  // namespace wanq
@@ -610,41 +724,14 @@ extern "C" int wanq_gemm_w8a8(const int8_t* a, const int8_t* w, void* out, int o
                               const void* asum, int tok_dtype, const void* sw, const void* bias, int ch_dtype,
                               const void* zp, int zp_dtype, const float* gate, const void* residual, int epi_flags,
                               int64_t M, int N, int K, void* stream) {
-  WANQ_REQUIRE(a && w && out, WANQ_E_ARG, "wanq_gemm_w8a8: a, w and out must be non-NULL");
-  WANQ_REQUIRE(out_dtype == WANQ_F16 || out_dtype == WANQ_BF16 || out_dtype == WANQ_F32 || out_dtype == WANQ_I32,
-               WANQ_E_ARG, "wanq_gemm_w8a8: bad out dtype %d", out_dtype);
-  WANQ_REQUIRE(M >= 0 && M < (1ll << 31) / 2, WANQ_E_SHAPE, "wanq_gemm_w8a8: M=%lld out of range", (long long)M);
-  WANQ_REQUIRE(N >= 8 && N % 8 == 0, WANQ_E_SHAPE, "wanq_gemm_w8a8: N=%d must be a positive multiple of 8", N);
-  WANQ_REQUIRE(K >= 16 && K % 16 == 0, WANQ_E_SHAPE, "wanq_gemm_w8a8: K=%d must be a positive multiple of 16", K);
-  if (out_dtype != WANQ_I32) {
-    WANQ_REQUIRE(sa && sw, WANQ_E_ARG, "wanq_gemm_w8a8: sa and sw are required for a floating output");
-    WANQ_REQUIRE(is_vec(tok_dtype) && is_vec(ch_dtype), WANQ_E_ARG, "wanq_gemm_w8a8: tok/ch dtype must be F16 or F32");
-    WANQ_REQUIRE(!zp || (asum && (zp_dtype == WANQ_I16 || zp_dtype == WANQ_F32)), WANQ_E_ARG,
-                 "wanq_gemm_w8a8: zp needs asum and dtype I16 or F32");
-    WANQ_REQUIRE(!(epi_flags & WANQ_EPI_GATE_RES) || (gate && residual), WANQ_E_ARG,
-                 "wanq_gemm_w8a8: WANQ_EPI_GATE_RES needs gate and residual");
-  } else {
-    WANQ_REQUIRE(epi_flags == 0, WANQ_E_ARG, "wanq_gemm_w8a8: int32 output takes no epilogue flags");
-  }
-  WANQ_REQUIRE((epi_flags & ~(WANQ_EPI_GELU | WANQ_EPI_GATE_RES)) == 0, WANQ_E_ARG, "wanq_gemm_w8a8: unknown epilogue flag");
-  if (M == 0) return WANQ_OK;
-  {
-    static const bool v1 = [] { const char* e = getenv("WANQ_GEMM_V1"); return e && e[0] == '1'; }();
-    g_force_v1 = v1;
-  }
-  static const int group_m = [] { const char* e = getenv("WANQ_GEMM_GROUP_M"); const int v = e ? atoi(e) : 0; return v > 0 ? v : GROUP_M; }();
-  GemmParams p{};
-  p.a = a; p.w = w; p.out = out; p.sa = sa; p.asum = asum; p.sw = sw; p.bias = bias; p.zp = zp; p.gate = gate;
-  p.residual = residual; p.tok_dtype = tok_dtype; p.ch_dtype = ch_dtype; p.zp_dtype = zp_dtype; p.epi = epi_flags;
-  p.M = (int)M; p.N = N; p.K = K; p.group_m = group_m;
-  p.mt = (int)((M + BM - 1) / BM);
-  p.nt = (N + BN - 1) / BN;
-  WANQ_REQUIRE((int64_t)p.mt * p.nt < (1ll << 31), WANQ_E_SHAPE, "wanq_gemm_w8a8: too many tiles");
-  hipStream_t st = (hipStream_t)stream;
-  switch (out_dtype) {
-    case WANQ_F16: return launch_gemm<WANQ_F16>(p, st);
-    case WANQ_BF16: return launch_gemm<WANQ_BF16>(p, st);
-    case WANQ_F32: return launch_gemm<WANQ_F32>(p, st);
-    default: return launch_gemm<WANQ_I32>(p, st);
-  }
+  return gemm_entry(false, a, w, out, out_dtype, sa, asum, tok_dtype, sw, bias, ch_dtype, zp, zp_dtype, gate, residual, epi_flags,
+                    M, N, K, stream);
+}
+
+extern "C" int wanq_gemm_w4a8(const int8_t* a, const uint8_t* w_packed, void* out, int out_dtype, const void* sa,
+                              const void* asum, int tok_dtype, const void* sw, const void* bias, int ch_dtype,
+                              const void* zp, int zp_dtype, const float* gate, const void* residual, int epi_flags,
+                              int64_t M, int N, int K, void* stream) {
+  return gemm_entry(true, a, w_packed, out, out_dtype, sa, asum, tok_dtype, sw, bias, ch_dtype, zp, zp_dtype, gate, residual,
+                    epi_flags, M, N, K, stream);
 }

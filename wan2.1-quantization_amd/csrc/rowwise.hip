@@ -531,56 +531,63 @@ extern "C" int wanq_weight_quant(const void* w, int w_dtype, const float* delta,
 }
 
 // ------------------------------------------------------------------------------ 4-bit weight storage
-// Packed layout (ours; the reference ships no packer and its QServe layout is an NVIDIA ldmatrix interleave):
-// row-major [N, K/2] bytes, byte j of a row = code[2j] | code[2j+1] << 4 with codes biased to unsigned 0..15.
-// Weights are a few MB per layer against hundreds of MB of activations, so W4 is a STORAGE format here: a
-// layer's codes are expanded to int8 once per call (or once at load) and run on the int8 MFMA kernel.
-__global__ __launch_bounds__(256) void pack_w4_kernel(const int8_t* q, uint8_t* packed, int bias, int64_t total16) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total16; i += (int64_t)gridDim.x * 256) {
-    const uint4 v = *reinterpret_cast<const uint4*>(q + i * 16);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    uint32_t o[2] = {0, 0};
-#pragma unroll
-    for (int b = 0; b < 16; ++b) {
-      const int c = (int)(int8_t)((w[b >> 2] >> (8 * (b & 3))) & 0xff) + bias;
-      o[b >> 3] |= (uint32_t)(c & 0xf) << (4 * (b & 7));
-    }
-    *reinterpret_cast<uint2*>(packed + i * 8) = make_uint2(o[0], o[1]);
+// Packed layout (ours; the reference ships no packer and its QServe layout is an NVIDIA ldmatrix interleave): row-major
+// [N, K/2] bytes, K % 32 == 0.  Each group of 32 consecutive codes takes 16 bytes = 4 dwords (P0a, P1a, P0b, P1b); for a
+// 16-code half e[0..15] (a = codes 0-15 of the group, b = codes 16-31), codes biased to unsigned nibbles u = e + bias:
+//     P0 byte i = u[i] | u[4+i] << 4,    P1 byte i = u[8+i] | u[12+i] << 4        (i = 0..3)
+// so that `P & 0x0f0f0f0f` and `(P >> 4) & 0x0f0f0f0f` ARE the four dwords of an int8 MFMA operand (16 consecutive k):
+// wanq_gemm_w4a8 reads 16 packed bytes per lane from LDS and gets two MFMA operands for six VALU instructions.
+__device__ __forceinline__ uint32_t w4_nibbles(uint32_t d, uint32_t flip) { return (d ^ flip) & 0x0f0f0f0fu; }
+
+__global__ __launch_bounds__(256) void pack_w4_kernel(const int8_t* q, uint8_t* packed, int bias, int64_t total32) {
+  const uint32_t flip = bias ? 0x08080808u : 0u;  // low nibble of (e + 8) = low nibble of e with bit 3 flipped
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total32; i += (int64_t)gridDim.x * 256) {
+    const uint4 a = *reinterpret_cast<const uint4*>(q + i * 32), b = *reinterpret_cast<const uint4*>(q + i * 32 + 16);
+    uint4 o;
+    o.x = w4_nibbles(a.x, flip) | (w4_nibbles(a.y, flip) << 4);
+    o.y = w4_nibbles(a.z, flip) | (w4_nibbles(a.w, flip) << 4);
+    o.z = w4_nibbles(b.x, flip) | (w4_nibbles(b.y, flip) << 4);
+    o.w = w4_nibbles(b.z, flip) | (w4_nibbles(b.w, flip) << 4);
+    *reinterpret_cast<uint4*>(packed + i * 16) = o;
   }
 }
 
-__global__ __launch_bounds__(256) void unpack_w4_kernel(const uint8_t* packed, int8_t* q, int bias, int64_t total16) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total16; i += (int64_t)gridDim.x * 256) {
-    const uint2 v = *reinterpret_cast<const uint2*>(packed + i * 8);
-    const uint32_t w[2] = {v.x, v.y};
-    uint32_t o[4] = {0, 0, 0, 0};
+__device__ __forceinline__ uint32_t w4_to_i8(uint32_t u4, int bias) {  // four unsigned nibbles (one per byte) -> int8 codes u - bias
+  uint32_t r = 0;
 #pragma unroll
-    for (int b = 0; b < 16; ++b) {
-      const int c = (int)((w[b >> 3] >> (4 * (b & 7))) & 0xf) - bias;
-      o[b >> 2] |= (uint32_t)(c & 0xff) << (8 * (b & 3));
-    }
-    *reinterpret_cast<uint4*>(q + i * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+  for (int b = 0; b < 4; ++b) r |= (uint32_t)(((int)((u4 >> (8 * b)) & 0xf) - bias) & 0xff) << (8 * b);
+  return r;
+}
+
+__global__ __launch_bounds__(256) void unpack_w4_kernel(const uint8_t* packed, int8_t* q, int bias, int64_t total32) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total32; i += (int64_t)gridDim.x * 256) {
+    const uint4 p = *reinterpret_cast<const uint4*>(packed + i * 16);
+    const uint32_t m = 0x0f0f0f0fu;
+    *reinterpret_cast<uint4*>(q + i * 32) =
+        make_uint4(w4_to_i8(p.x & m, bias), w4_to_i8((p.x >> 4) & m, bias), w4_to_i8(p.y & m, bias), w4_to_i8((p.y >> 4) & m, bias));
+    *reinterpret_cast<uint4*>(q + i * 32 + 16) =
+        make_uint4(w4_to_i8(p.z & m, bias), w4_to_i8((p.z >> 4) & m, bias), w4_to_i8(p.w & m, bias), w4_to_i8((p.w >> 4) & m, bias));
   }
 }
 
 extern "C" int wanq_pack_w4(const int8_t* q, uint8_t* packed, int bias, int64_t rows, int cols, void* stream) {
   WANQ_REQUIRE(q && packed, WANQ_E_ARG, "wanq_pack_w4: NULL pointer");
-  WANQ_REQUIRE(cols >= 16 && cols % 16 == 0, WANQ_E_SHAPE, "wanq_pack_w4: cols=%d must be a multiple of 16", cols);
-  WANQ_REQUIRE(rows >= 0 && bias >= 0 && bias <= 8, WANQ_E_ARG, "wanq_pack_w4: bad rows / bias");
-  const int64_t total16 = rows * (cols / 16);
-  if (total16 == 0) return WANQ_OK;
-  const unsigned grid = (unsigned)((total16 + 255) / 256 < 4096 ? (total16 + 255) / 256 : 4096);
-  hipLaunchKernelGGL(pack_w4_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, q, packed, bias, total16);
+  WANQ_REQUIRE(cols >= 32 && cols % 32 == 0, WANQ_E_SHAPE, "wanq_pack_w4: cols=%d must be a multiple of 32", cols);
+  WANQ_REQUIRE(rows >= 0 && (bias == 0 || bias == 8), WANQ_E_ARG, "wanq_pack_w4: bias must be 0 (unsigned codes) or 8 (signed codes)");
+  const int64_t total32 = rows * (cols / 32);
+  if (total32 == 0) return WANQ_OK;
+  const unsigned grid = (unsigned)((total32 + 255) / 256 < 4096 ? (total32 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_w4_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, q, packed, bias, total32);
   return check_launch("wanq_pack_w4");
 }
 
 extern "C" int wanq_unpack_w4(const uint8_t* packed, int8_t* q, int bias, int64_t rows, int cols, void* stream) {
   WANQ_REQUIRE(q && packed, WANQ_E_ARG, "wanq_unpack_w4: NULL pointer");
-  WANQ_REQUIRE(cols >= 16 && cols % 16 == 0, WANQ_E_SHAPE, "wanq_unpack_w4: cols=%d must be a multiple of 16", cols);
-  WANQ_REQUIRE(rows >= 0 && bias >= 0 && bias <= 8, WANQ_E_ARG, "wanq_unpack_w4: bad rows / bias");
-  const int64_t total16 = rows * (cols / 16);
-  if (total16 == 0) return WANQ_OK;
-  const unsigned grid = (unsigned)((total16 + 255) / 256 < 4096 ? (total16 + 255) / 256 : 4096);
-  hipLaunchKernelGGL(unpack_w4_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, packed, q, bias, total16);
+  WANQ_REQUIRE(cols >= 32 && cols % 32 == 0, WANQ_E_SHAPE, "wanq_unpack_w4: cols=%d must be a multiple of 32", cols);
+  WANQ_REQUIRE(rows >= 0 && (bias == 0 || bias == 8), WANQ_E_ARG, "wanq_unpack_w4: bias must be 0 (unsigned codes) or 8 (signed codes)");
+  const int64_t total32 = rows * (cols / 32);
+  if (total32 == 0) return WANQ_OK;
+  const unsigned grid = (unsigned)((total32 + 255) / 256 < 4096 ? (total32 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(unpack_w4_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, packed, q, bias, total32);
   return check_launch("wanq_unpack_w4");
 }

@@ -59,8 +59,14 @@ class StaticQuantizer(BaseQuantizer):
         if self.init_done is not True:
             self.init_quant_params(x)
         n = self.n_levels
-        return fused.weight_quant(x.contiguous(), self.delta.reshape(-1).float().contiguous(),
-                                  self.zero_point.reshape(-1).float().contiguous(), -n - 1, n, want_codes, want_dequant)
+        codes, deq = fused.weight_quant(x.contiguous(), self.delta.reshape(-1).float().contiguous(),
+                                        self.zero_point.reshape(-1).float().contiguous(), -n - 1, n, want_codes, want_dequant)
+        if codes is not None and self.n_bits < 8:
+            # The reference's clamp is one level looser than the bit-width: a row whose extremes tie exactly at a
+            # .5 boundary (lo = -hi, e.g. lattice-valued rotated weights) produces a 17th level.  Integer STORAGE has 2^b
+            # levels, so the codes saturate; the fake-quant `weight.data` keeps the reference's value.
+            codes.clamp_(-(2 ** (self.n_bits - 1)), 2 ** (self.n_bits - 1) - 1)
+        return codes, deq
 
     def quantize(self, x):
         return self.codes_and_dequant(x, True, False)[0].float()

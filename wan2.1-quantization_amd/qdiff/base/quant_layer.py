@@ -31,7 +31,8 @@ class QuantizedLinear(nn.Linear):
         self.channel_mask = None
         self.rotation_signs = None
         self._premul = self._rot = None
-        self.register_buffer("int_weight", None, persistent=False)
+        self.register_buffer("_codes", None, persistent=False)  # int8 [N,K], or uint8 [N,K/2] packed nibbles (4-bit weights)
+        self._zp_gemm = None
         if quant_config.get("weight", None) is not None:
             wq = quant_config["weight"]
             self.w_quantizer = (MixedPrecisionStaticQuantizer if isinstance(wq["n_bits"], ListConfig) else StaticQuantizer)(wq)
@@ -54,6 +55,26 @@ class QuantizedLinear(nn.Linear):
         codes, deq = self.w_quantizer.codes_and_dequant(w.detach().float())
         self.weight.data = deq
         self.int_weight = codes
+
+    @property
+    def packed_w4(self):
+        return self.w_quantizer is not None and self.w_quantizer.n_bits == 4 and self.in_features % 32 == 0
+
+    @property
+    def int_weight(self):
+        """int8 codes [N, K].  4-bit layers keep them PACKED in HBM (two per byte, qgemm.pack_w4 layout); this view unpacks."""
+        c = self._codes
+        if c is not None and c.dtype == torch.uint8:
+            return qgemm.unpack_w4(c, bias=8)
+        return c
+
+    @int_weight.setter
+    def int_weight(self, codes):
+        if codes is not None and self.packed_w4:
+            self._codes = qgemm.pack_w4(codes.contiguous(), bias=8)
+        else:
+            self._codes = codes
+        self._zp_gemm = None
 
     def refresh(self):
         """Re-derive the quantized weight after the quantizer changed (bitwidth_refactor, load): the SAME derivation the
@@ -102,9 +123,14 @@ class QuantizedLinear(nn.Linear):
         wq = self.w_quantizer
         zp = None if wq.sym else wq.zero_point.reshape(-1).float().contiguous()
         out_dtype = x.dtype if x.dtype in (torch.float16, torch.bfloat16, torch.float32) else torch.float32
-        y = qgemm.w8a8_linear(q, self.int_weight, scale, wq.delta.reshape(-1).float().contiguous(),
+        w4 = self._codes.dtype == torch.uint8
+        if w4:  # nibbles are stored as code + 8: fold the 8 into the zero point of the epilogue
+            if self._zp_gemm is None:
+                self._zp_gemm = ((zp if zp is not None else torch.zeros_like(wq.delta.reshape(-1).float())) - 8.0).contiguous()
+            zp = self._zp_gemm
+        y = qgemm.w8a8_linear(q, self._codes, scale, wq.delta.reshape(-1).float().contiguous(),
                               None if self.bias is None else self.bias.detach().float().contiguous(),
-                              ssum if zp is not None else None, zp, out_dtype=out_dtype)
+                              ssum if zp is not None else None, zp, out_dtype=out_dtype, w4=w4)
         return y.view(*shape[:-1], self.out_features)
 
     # ---- PTQ hooks shared by the variants ------------------------------------------------------------

@@ -42,15 +42,25 @@ def _check_vec(name, t, n, dtypes=_VEC):
 
 
 def w8a8_linear(input, weight, scale_input, scale_weight, bias=None, input_sum=None, zp_weight=None,
-                out_dtype=torch.float16, gelu=False, gate=None, residual=None, out=None):
+                out_dtype=torch.float16, gelu=False, gate=None, residual=None, out=None, w4=False):
     """General entry: y = epilogue(int8 input[M,K] @ int8 weight[N,K]^T); see include/wanq_hip.h.
 
-    gate (fp32 [N]) + residual ([M,N], out dtype): y = residual + y * gate (may alias `out`)."""
+    gate (fp32 [N]) + residual ([M,N], out dtype): y = residual + y * gate (may alias `out`).
+    w4=True: `weight` is uint8 [N, K/2], unsigned 4-bit codes in the pack_w4 layout (wanq_gemm_w4a8)."""
     _check_i8("input", input)
     M, K = input.shape
-    _check_i8("weight", weight)
-    N = weight.shape[0]
-    _C.check_shape("weight", weight, N, K)
+    if w4:
+        _C.check_gpu("weight", weight)
+        _C.check_contig("weight", weight)
+        _C.check_dtype("weight", weight, torch.uint8)
+        N = weight.shape[0]
+        _C.check_shape("weight", weight, N, K // 2)
+        if K % 32:
+            raise RuntimeError(f"w4a8: K={K} must be a multiple of 32")
+    else:
+        _check_i8("weight", weight)
+        N = weight.shape[0]
+        _C.check_shape("weight", weight, N, K)
     _check_vec("scale_input", scale_input, M)
     _check_vec("scale_weight", scale_weight, N)
     _check_vec("bias", bias, N)
@@ -84,7 +94,7 @@ def w8a8_linear(input, weight, scale_input, scale_weight, bias=None, input_sum=N
         if _timer is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        _C.call("wanq_gemm_w8a8", _C.ptr(input), _C.ptr(weight), _C.ptr(out), _C.dt(out_dtype), _C.ptr(scale_input),
+        _C.call("wanq_gemm_w4a8" if w4 else "wanq_gemm_w8a8", _C.ptr(input), _C.ptr(weight), _C.ptr(out), _C.dt(out_dtype), _C.ptr(scale_input),
                 _C.ptr(input_sum), _C.dt(scale_input), _C.ptr(scale_weight), _C.ptr(bias), _C.dt(scale_weight),
                 _C.ptr(zp_weight), _C.dt(zp_weight) if zp_weight is not None else _C.F32, _C.ptr(gate),
                 _C.ptr(residual), epi, M, N, K, _C.stream())
@@ -124,9 +134,10 @@ def w8a8_o32(input, weight):
     return out
 
 
-# ---- W4 storage -------------------------------------------------------------------------------------------------
+# ---- W4 -----------------------------------------------------------------------------------------------------------
 def pack_w4(codes, bias=8):
-    """int8 codes [N, K] (signed [-8,7] with bias 8, or unsigned 0..15 with bias 0) -> uint8 [N, K/2]."""
+    """int8 codes [N, K] (signed [-8,7] with bias 8, or unsigned 0..15 with bias 0) -> uint8 [N, K/2] in the library's
+    packed layout (include/wanq_hip.h: 32 codes -> 16 bytes arranged as int8-MFMA operand nibbles)."""
     _check_i8("codes", codes)
     N, K = codes.shape
     out = torch.empty((N, K // 2), dtype=torch.uint8, device=codes.device)
@@ -147,13 +158,26 @@ def unpack_w4(packed, bias=8):
     return out
 
 
+def w4a8_o32(input, kernel):
+    """Raw int32 accumulators of int8 input [M, K] x unsigned 4-bit codes (packed uint8 [N, K/2])."""
+    _check_i8("input", input)
+    M, K = input.shape
+    N = kernel.shape[0]
+    _C.check_dtype("kernel", kernel, torch.uint8)
+    _C.check_shape("kernel", kernel, N, K // 2)
+    out = torch.empty((M, N), dtype=torch.int32, device=input.device)
+    with torch.cuda.device(input.device):
+        _C.call("wanq_gemm_w4a8", _C.ptr(input), _C.ptr(kernel), _C.ptr(out), _C.I32, None, None, _C.F32, None, None,
+                _C.F32, None, _C.F32, None, None, 0, M, N, K, _C.stream())
+    return out
+
+
 def w4a8_of16_nobias_weight_asym_qserve(in_feats, kernel, wscales, ascales, w_szs, a_ssums, out_feats):
     """Reference signature (ViDiT-Q/kernels/csrc/qgemm/pybind.cpp:12): writes out_feats (fp16 [M, N]).
     kernel: UNSIGNED 4-bit codes packed two per byte, uint8 [N, K/2] in THIS library's layout (pack_w4(..., bias=0));
     y = acc * wscales[n] * ascales[m] - w_szs[n] * a_ssums[m]  with w_szs = scale*zero
-    (w4a8_per_channel_gemm_cuda_qserve.cu:580-587)."""
-    codes = unpack_w4(kernel, bias=0)
+    (w4a8_per_channel_gemm_cuda_qserve.cu:580-587).  The nibbles are expanded in registers inside the GEMM."""
     vec = ascales.dtype
     zp = (-(w_szs.float() / wscales.float())).contiguous()  # asym epilogue: + a_ssum * zp * wscale
-    y = w8a8_linear(in_feats, codes, ascales, wscales.to(vec), None, a_ssums, zp.float(), out_dtype=out_feats.dtype)
-    out_feats.copy_(y)
+    w8a8_linear(in_feats, kernel, ascales, wscales.to(vec), None, a_ssums, zp.float(), out_dtype=out_feats.dtype, out=out_feats,
+                w4=True)

@@ -82,7 +82,8 @@ class QuantWanModel(WanModel, QuantModel):
                     if mod.bias is not None:
                         sd[name + ".bias"] = mod.bias.detach().to(f16).clone()
                 else:
-                    sd[name + ".weight"] = mod.int_weight.clone()
+                    # 8-bit: int8 [N, K]; 4-bit: uint8 [N, K/2], the packed nibbles exactly as the GEMM reads them
+                    sd[name + ".weight"] = mod._codes.clone()
                     sd[name + ".scale_weight"] = wq.delta.reshape(-1).float().clone()
                     if not wq.sym:
                         sd[name + ".zp_weight"] = wq.zero_point.reshape(-1).float().clone()
@@ -136,10 +137,11 @@ class QuantWanModel(WanModel, QuantModel):
                         if dst is None:
                             raise KeyError(f"{load_path}: {base}.{k} present but the model's layer has no {buf}")
                         src = sd[f"{base}.{k}"]
-                        if tuple(src.shape) != tuple(dst.shape) or (buf == "weight" and src.dtype != torch.int8):
-                            raise ValueError(f"{load_path}: {base}.{k} is {tuple(src.shape)} {src.dtype}, expected {tuple(dst.shape)}")
+                        if tuple(src.shape) != tuple(dst.shape) or (buf == "weight" and src.dtype != dst.dtype):
+                            raise ValueError(f"{load_path}: {base}.{k} is {tuple(src.shape)} {src.dtype}, expected {tuple(dst.shape)} {dst.dtype}")
                         dst.copy_(src.to(dst.dtype))
                         taken += 1
+                    lin.refresh_zp_gemm()
             logger.info("loaded %d tensors of the integer checkpoint %s into the kernel-mode blocks", taken, load_path)
         return self
 

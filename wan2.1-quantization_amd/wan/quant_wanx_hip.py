@@ -22,18 +22,27 @@ from .modules.model import WanModel
 
 
 class HipLinearW8A8(nn.Module):
-    """int8 weight [N,K] + per-output-channel fp32 (delta, zero_point) + fp32 bias.
+    """Integer weight + per-output-channel fp32 (delta, zero_point) + fp32 bias.
     weight_dequant = (code + zero_point) * delta  (StaticQuantizer.forward, qdiff/base/base_quantizer.py:56-59).
+    w_bits 8: `weight` int8 [N, K].  w_bits 4: `weight` uint8 [N, K/2], the codes + 8 as nibbles in the library's packed layout
+    (include/wanq_hip.h); they stay packed in HBM and are expanded in registers inside the GEMM (wanq_gemm_w4a8), the +8 being
+    folded into the zero point the epilogue uses (`zp_gemm` = zero_point - 8).
     Optional ViDiT activation transform: `act_premul` fp32 [K] (= channel_mask * rotation signs) and `rot`
     (had_k, hadk) -- the producer kernel applies hadU(x * premul) before quantising this layer's input."""
     quantized = True
 
-    def __init__(self, in_features, out_features, bias=True, sym=False):
+    def __init__(self, in_features, out_features, bias=True, sym=False, w_bits=8):
         super().__init__()
-        self.in_features, self.out_features = in_features, out_features
-        self.register_buffer("weight", torch.empty(out_features, in_features, dtype=torch.int8))
+        assert w_bits in (4, 8), "integer storage exists for 8-bit and packed 4-bit weights"
+        self.in_features, self.out_features, self.w_bits = in_features, out_features, w_bits
+        if w_bits == 4:
+            assert in_features % 32 == 0, "packed 4-bit weights need in_features % 32 == 0"
+            self.register_buffer("weight", torch.empty(out_features, in_features // 2, dtype=torch.uint8))
+        else:
+            self.register_buffer("weight", torch.empty(out_features, in_features, dtype=torch.int8))
         self.register_buffer("scale_weight", torch.empty(out_features, dtype=torch.float32))
         self.register_buffer("zp_weight", None if sym else torch.empty(out_features, dtype=torch.float32))
+        self.register_buffer("zp_gemm", torch.empty(out_features, dtype=torch.float32) if w_bits == 4 else None)
         self.register_buffer("bias", torch.empty(out_features, dtype=torch.float32) if bias else None)
         self.register_buffer("act_premul", None)
         self.rot = None
@@ -45,18 +54,31 @@ class HipLinearW8A8(nn.Module):
 
         return static_params(w, n_bits, sym)
 
+    def _set_codes(self, codes, delta, zero_point):
+        """codes: int8 [N, K] in [-2^(b-1), 2^(b-1)-1]."""
+        if self.w_bits == 4:
+            self.weight.copy_(qgemm.pack_w4(codes.clamp(-8, 7).contiguous(), bias=8))
+            self.zp_gemm.copy_((zero_point if zero_point is not None else torch.zeros_like(delta)) - 8.0)
+        else:
+            self.weight.copy_(codes)
+        self.scale_weight.copy_(delta)
+        if self.zp_weight is not None:
+            self.zp_weight.copy_(zero_point)
+
+    def refresh_zp_gemm(self):
+        """After scale_weight / zp_weight were loaded from a checkpoint."""
+        if self.w_bits == 4:
+            self.zp_gemm.copy_((self.zp_weight if self.zp_weight is not None else torch.zeros_like(self.scale_weight)) - 8.0)
+
     @classmethod
     def from_float(cls, weight, bias=None, n_bits=8, sym=False, delta=None, zero_point=None):
         weight = weight.detach().float().contiguous()
-        m = cls(weight.shape[1], weight.shape[0], bias is not None, sym).to(weight.device)
+        m = cls(weight.shape[1], weight.shape[0], bias is not None, sym, n_bits).to(weight.device)
         if delta is None:
             delta, zero_point = cls.quant_params(weight, n_bits, sym)
         delta, zero_point = delta.float().contiguous().view(-1), zero_point.float().contiguous().view(-1)
         codes, _ = fused.weight_quant(weight, delta, zero_point, -128, 127)
-        m.weight.copy_(codes)
-        m.scale_weight.copy_(delta)
-        if not sym:
-            m.zp_weight.copy_(zero_point)
+        m._set_codes(codes, delta, None if sym else zero_point)
         if bias is not None:
             m.bias.copy_(bias.detach().float())
         return m
@@ -65,11 +87,8 @@ class HipLinearW8A8(nn.Module):
     def from_quantized(cls, ql):
         """From a qdiff QuantizedLinear (any variant): same integer codes, same parameters, same transform."""
         wq = ql.w_quantizer
-        m = cls(ql.in_features, ql.out_features, ql.bias is not None, wq.sym).to(ql.int_weight.device)
-        m.weight.copy_(ql.int_weight)
-        m.scale_weight.copy_(wq.delta.reshape(-1).float())
-        if not wq.sym:
-            m.zp_weight.copy_(wq.zero_point.reshape(-1).float())
+        m = cls(ql.in_features, ql.out_features, ql.bias is not None, wq.sym, wq.n_bits).to(ql.fp_module.weight.device)
+        m._set_codes(ql.int_weight, wq.delta.reshape(-1).float(), None if wq.sym else wq.zero_point.reshape(-1).float())
         if ql.bias is not None:
             m.bias.copy_(ql.bias.detach().float())
         premul, rot = ql._act_transform()
@@ -82,6 +101,9 @@ class HipLinearW8A8(nn.Module):
         return None if self.act_premul is None and self.rot is None else id(self)
 
     def forward(self, a_q, a_scale, a_sum, out_dtype=torch.bfloat16, gelu=False, gate=None, residual=None, out=None):
+        if self.w_bits == 4:
+            return qgemm.w8a8_linear(a_q, self.weight, a_scale, self.scale_weight, self.bias, a_sum, self.zp_gemm,
+                                     out_dtype=out_dtype, gelu=gelu, gate=gate, residual=residual, out=out, w4=True)
         return qgemm.w8a8_linear(a_q, self.weight, a_scale, self.scale_weight, self.bias,
                                  a_sum if self.zp_weight is not None else None, self.zp_weight, out_dtype=out_dtype,
                                  gelu=gelu, gate=gate, residual=residual, out=out)
