@@ -200,5 +200,6 @@ def test_w4a8_epilogue_matches_w8a8_on_unpacked_codes():
         y8 = qgemm().w8a8_linear(a, t(q), sa, sw, bias, asum, zp, **kw)
         y4 = qgemm().w8a8_linear(a, packed, sa, sw, bias, asum, zp - 8.0, w4=True, **kw)
         # acc_u + (zp - 8) * sum  vs  acc_q + zp * sum: the same value through different fp32 roundings -> 1 ulp of the output type
-        tol = 1e-5 if kw["out_dtype"] == torch.float32 else 1e-2
-        assert torch.allclose(y4.float(), y8.float(), rtol=tol, atol=tol), (y4.float() - y8.float()).abs().max()
+        # (the +8 bias makes acc_u larger than acc_q and cancels in the zero-point term: ~1e-6 of the largest term in fp32)
+        tol = 1e-4 if kw["out_dtype"] == torch.float32 else 1e-2
+        assert torch.allclose(y4.float(), y8.float(), rtol=tol, atol=tol * float(y8.float().abs().max())), (y4.float() - y8.float()).abs().max()
