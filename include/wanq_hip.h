@@ -135,6 +135,17 @@ int wanq_rmsnorm_rope(const void* x, int x_dtype, const float* weight, const flo
                       int out_dtype, int64_t rows, int cols, int head_dim, int64_t rows_per_batch,
                       int64_t positions, float eps, void* stream);
 
+/* The same, additionally (or only: out may be NULL) emitting the row as per-(token, head) symmetric int8 codes for the int8
+ * Q.K^T attention below: for every head slice of 128 columns  delta = max(absmax / 127, 1e-6),  q8 = clamp(rne(y / delta))
+ * -- DynamicQuantizer on [tokens*heads, head_dim] rows, the q / k recipe of the reference's quantized attention
+ * (ViDiT-Q/quant_utils/qdiff/base/quant_attn.py:168-174, examples/Wan2.1/models/quant_opensora.py:431-436).
+ * q8: int8 [rows, cols].  qscale: fp32, two planes of [cols/128][scale_stride]: delta[h][row], then -12582912 * delta[h][row]
+ * (the constant of the attention kernel's dequantising fma); scale_stride >= rows (for keys: rows rounded up to 64).
+ * head_dim must be 128. */
+int wanq_rmsnorm_rope_q8(const void* x, int x_dtype, const float* weight, const float* rope, void* out,
+                         int out_dtype, int8_t* q8, float* qscale, int64_t scale_stride, int64_t rows, int cols,
+                         int head_dim, int64_t rows_per_batch, int64_t positions, float eps, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Flash-attention forward, non-causal:  o[q,h,:] = softmax_k(q[q,h,:].k[k,h,:] * scale) v[k,h,:] over the
  * first Lk keys.  Token-major tensors [tokens, heads*head_dim] with a token stride in ELEMENTS (so q/k/v may
@@ -156,6 +167,19 @@ int wanq_attention_fwd_split(const void* q, const void* k, const void* v, void* 
                              int64_t Lk, int heads, int head_dim, int64_t q_stride, int64_t k_stride,
                              int64_t v_stride, int64_t o_stride, float scale, int splits, void* workspace,
                              int64_t workspace_bytes, void* stream);
+
+/* Quantized Q.K^T (the reference's `attn.qk` fake-quant recipe, quant_attn.py:168-174, run on the integer matrix cores):
+ *   o[q,h,:] = softmax_k( (q8[q,h,:] . k8[k,h,:]) * delta_q[h][q] * delta_k[h][k] * scale ) v[k,h,:]
+ * q8 / k8: int8 [tokens, heads*128] with byte strides q8_stride / k8_stride; q_scale: fp32 [heads][qs_stride]; k_scale: fp32
+ * two planes [heads][ks_stride] (delta_k, then -12582912*delta_k: the layout wanq_rmsnorm_rope_q8 writes), ks_stride >= Lk
+ * rounded up to 64.  S = K8.Q8^T on v_mfma_i32_32x32x32_i8 (integer-exact), P.V in bf16 as above; v / o bf16.
+ * splits as in wanq_attention_fwd_split (1 = none; workspace from wanq_attention_split_workspace).
+ * The reference wires this recipe for OpenSORA only (Q/base/quant_attn.py is imported, not used, by its Wan model). */
+int wanq_attention_qk8_fwd(const int8_t* q8, const float* q_scale, int64_t qs_stride, const int8_t* k8,
+                           const float* k_scale, int64_t ks_stride, const void* v, void* o, int dtype, int64_t Lq,
+                           int64_t Lk, int heads, int head_dim, int64_t q8_stride, int64_t k8_stride,
+                           int64_t v_stride, int64_t o_stride, float scale, int splits, void* workspace,
+                           int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * ViDiT activation transform fused with the per-token quantiser:

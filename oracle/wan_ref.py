@@ -115,11 +115,25 @@ def attention(q, k, v, k_len=None):
     return torch.einsum("nqk,knd->qnd", torch.softmax(s, dim=-1), v)
 
 
+def qk_fake_quant(x, n_bits=8):
+    """The reference's q / k quantisation for quantized attention: DynamicQuantizer over head_dim for every (token, head) --
+    `self.q_quantizer(q.reshape([-1, N_dim]))` (W/models/quant_opensora.py:431-436; quantizers built from
+    quant_config.attn.qk, Q/base/quant_attn.py:168-174).  x [L, n, d] fp32 -> fake-quantised fp32."""
+    L, n, d = x.shape
+    return dyn_fake_quant(x.reshape(L * n, d), n_bits).reshape(L, n, d)
+
+
+def attention_qk_quant(q, k, v, k_len=None, n_bits=8):
+    """attention() on fake-quantised q and k (post-RoPE, pre-scale, as the reference places the quantizers)."""
+    return attention(qk_fake_quant(q, n_bits), qk_fake_quant(k, n_bits), v, k_len)
+
+
 class BlockRef:
     """One WanAttentionBlock in simulation mode.  `lin` maps 'self_attn.q' ... 'ffn.2' to callables."""
 
-    def __init__(self, lin, norm_w, modulation, num_heads, eps=1e-6, norm3=None):
+    def __init__(self, lin, norm_w, modulation, num_heads, eps=1e-6, norm3=None, qk_bits=None, cross_qk_bits=None):
         self.lin, self.norm_w, self.mod, self.n, self.eps, self.norm3 = lin, norm_w, modulation.float(), num_heads, eps, norm3
+        self.qk_bits, self.cross_qk_bits = qk_bits, cross_qk_bits  # None = FP attention (the reference's Wan wiring)
 
     def __call__(self, x, e0, grid, seq_len, context, freqs):
         """x [L, C], e0 [1, 6, C], context [Lc, C] -> x' [L, C]   (model.py:293-370 for B = 1)."""
@@ -131,12 +145,17 @@ class BlockRef:
         q = rms_norm(self.lin["self_attn.q"](h), self.norm_w["self_attn.norm_q"], self.eps).view(L, n, d)
         k = rms_norm(self.lin["self_attn.k"](h), self.norm_w["self_attn.norm_k"], self.eps).view(L, n, d)
         v = self.lin["self_attn.v"](h).view(L, n, d)
-        o = attention(rope_apply(q, grid, freqs), rope_apply(k, grid, freqs), v, seq_len).reshape(L, C)
+        q, k = rope_apply(q, grid, freqs), rope_apply(k, grid, freqs)
+        if self.qk_bits:
+            q, k = qk_fake_quant(q, self.qk_bits), qk_fake_quant(k, self.qk_bits)
+        o = attention(q, k, v, seq_len).reshape(L, C)
         x = x + self.lin["self_attn.o"](o) * e[2]
         h = layer_norm(x, self.eps, *(self.norm3 or (None, None)))
         q = rms_norm(self.lin["cross_attn.q"](h), self.norm_w["cross_attn.norm_q"], self.eps).view(L, n, d)
         k = rms_norm(self.lin["cross_attn.k"](context), self.norm_w["cross_attn.norm_k"], self.eps).view(-1, n, d)
         v = self.lin["cross_attn.v"](context).view(-1, n, d)
+        if self.cross_qk_bits:
+            q, k = qk_fake_quant(q, self.cross_qk_bits), qk_fake_quant(k, self.cross_qk_bits)
         x = x + self.lin["cross_attn.o"](attention(q, k, v).reshape(L, C))
         h = layer_norm(x, self.eps) * (1 + e[4]) + e[3]
         y = self.lin["ffn.2"](F.gelu(self.lin["ffn.0"](h), approximate="tanh"))
@@ -147,7 +166,7 @@ LINEARS = ("self_attn.q", "self_attn.k", "self_attn.v", "self_attn.o", "cross_at
            "cross_attn.o", "ffn.0", "ffn.2")
 
 
-def block_from_state(sd, num_heads, eps=1e-6, quant=True, w_bits=8, a_bits=8, vidit=None):
+def block_from_state(sd, num_heads, eps=1e-6, quant=True, w_bits=8, a_bits=8, vidit=None, qk_bits=None, cross_qk_bits=None):
     """Build a BlockRef from a WanAttentionBlock state dict (CPU tensors).
     vidit: optional {linear name: (channel_mask fp32 [K], rotation fp64 [K,K])}."""
     lin = {}
@@ -160,4 +179,4 @@ def block_from_state(sd, num_heads, eps=1e-6, quant=True, w_bits=8, a_bits=8, vi
             lin[name] = FpLinear(w, b)
     norm_w = {k: sd[k + ".weight"].float() for k in ("self_attn.norm_q", "self_attn.norm_k", "cross_attn.norm_q", "cross_attn.norm_k")}
     norm3 = (sd["norm3.weight"].float(), sd["norm3.bias"].float()) if "norm3.weight" in sd else None
-    return BlockRef(lin, norm_w, sd["modulation"], num_heads, eps, norm3)
+    return BlockRef(lin, norm_w, sd["modulation"], num_heads, eps, norm3, qk_bits, cross_qk_bits)

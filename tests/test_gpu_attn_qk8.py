@@ -1,0 +1,143 @@
+"""Quantized Q.K^T attention: per-(token, head) symmetric int8 q / k, score matrix on the int8 matrix cores.
+Oracle: the reference's recipe restated in oracle/wan_ref.py (qk_fake_quant / attention_qk_quant -- DynamicQuantizer over
+head_dim for every (token, head), W/models/quant_opensora.py:431-436, Q/base/quant_attn.py:168-174) with fp32 softmax."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import qdiff_ref as qr
+from oracle import wan_ref as wr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rand(L, H, seed, spread=True):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(L, H * 128, generator=g)
+    if spread:  # per-channel spread + a few outlier tokens, so that per-(token, head) scales really differ
+        x = x * torch.exp(0.5 * torch.randn(H * 128, generator=g))
+        x[:: max(1, L // 7)] *= 4.0
+    return x
+
+
+@pytest.mark.parametrize("L,H,dtype", [(70, 2, torch.float32), (300, 12, torch.bfloat16), (9, 40, torch.bfloat16)])
+def test_rmsnorm_rope_q8_codes_and_scales_vs_oracle(L, H, dtype):
+    """int8 codes / scales of the fused RMSNorm + RoPE + per-head quantiser vs the oracle chain rms_norm -> rope_apply (float64
+    rotation) -> DynamicQuantizer on [tokens*heads, 128]: scales 1e-5 rel, codes within 1 LSB on < 0.5 % of the elements (the
+    kernel normalises and rotates in fp32: codes move only at .5 boundaries); the constant plane is -12582912 * scale exactly."""
+    from wan import ops
+
+    C, d = H * 128, 128
+    x = _rand(L, H, L + H).to(dtype)
+    w = torch.rand(C, generator=torch.Generator().manual_seed(1)) + 0.5
+    grid = (1, 3, L // 3) if L % 3 == 0 else (1, 1, L)
+    freqs = wr.rope_freqs(d)
+    table = ops.rope_table(freqs, grid, DEV)
+    q8, fp = ops.rmsnorm_rope_q8(x.to(DEV), w.to(DEV), table, d, True, want_fp=True)
+    assert q8.stride % 64 == 0 and q8.stride >= L
+    ref = wr.rope_apply(wr.rms_norm(x.float(), w, 1e-6).view(L, H, d), grid, freqs)          # [L, H, d] fp32
+    oq, oscale = qr.dynamic_quantize_sym(ref.reshape(L * H, d).numpy())
+    scale = q8.scales[0, :, :L].t().contiguous().cpu().numpy().reshape(-1)                      # [L*H]
+    np.testing.assert_allclose(scale, oscale.reshape(-1), rtol=2e-5)
+    np.testing.assert_array_equal(q8.scales[1, :, :L].cpu().numpy(), (-12582912.0 * q8.scales[0, :, :L]).cpu().numpy())
+    dq = np.abs(q8.codes.cpu().numpy().astype(np.int32).reshape(L * H, d) - oq.astype(np.int32))
+    assert dq.max() <= 1 and (dq != 0).mean() < 5e-3, (dq.max(), (dq != 0).mean())
+    # the bf16 row written beside the codes is what the plain kernel writes
+    plain = ops.rmsnorm_rope_(x.to(DEV).clone(), w.to(DEV), table, d, out=torch.empty(L, C, dtype=torch.bfloat16, device=DEV))
+    assert torch.equal(fp, plain)
+
+
+def _ref_from_codes(q8, k8, v, H, k_len=None):
+    """fp32 definition on the kernel's own codes: softmax((q8*dq)(k8*dk)^T / sqrt(d)) v."""
+    Lq, Lk = q8.codes.shape[0], k8.codes.shape[0]
+    q = q8.codes.float().view(Lq, H, 128) * q8.scales[0, :, :Lq].t().unsqueeze(-1)
+    k = k8.codes.float().view(Lk, H, 128) * k8.scales[0, :, :Lk].t().unsqueeze(-1)
+    return wr.attention(q.cpu(), k.cpu(), v.float().view(Lk, H, 128).cpu(), k_len).reshape(Lq, H * 128)
+
+
+@pytest.mark.parametrize("Lq,Lk,H,klen,splits", [(256, 256, 2, None, 1), (300, 333, 3, None, 1), (513, 700, 2, 650, 1),
+                                                (64, 40, 4, None, 1), (1000, 4096, 2, None, 1), (520, 4100, 1, 4000, 3),
+                                                (4680, 4680, 12, None, None)])
+def test_attention_qk8_vs_fp32_definition(Lq, Lk, H, klen, splits):
+    """Ragged query / key counts, key-length masking, a short (cross-attention-like) key set, split-KV, and the cfg-A size."""
+    from wan import ops
+
+    w = torch.ones(H * 128, device=DEV)
+    q8 = ops.rmsnorm_rope_q8(_rand(Lq, H, 1).to(DEV), w, None, 128, False)
+    k8 = ops.rmsnorm_rope_q8(_rand(Lk, H, 2).to(DEV), w, None, 128, True)
+    v = _rand(Lk, H, 3, spread=False).to(torch.bfloat16).to(DEV)
+    out = ops.attention_qk8(q8, k8, v, H, klen, splits=splits).float().cpu()
+    ref = _ref_from_codes(q8, k8, v, H, klen)
+    assert float((out - ref).abs().max()) < 3e-2 and float((out - ref).norm() / ref.norm()) < 1e-2
+    if splits and splits > 1:
+        one = ops.attention_qk8(q8, k8, v, H, klen, splits=1).float().cpu()
+        assert float((out - one).abs().max()) < 2e-2
+
+
+def test_attention_qk8_integer_scores_are_exact():
+    """Peaked scores: with codes +-127 on one matching key per query the int8 dot is 128*127*127 = 2064512 (the largest
+    magnitude the magic-number accumulator has to carry) and softmax puts all the mass there: o[q] == v[key(q)] exactly."""
+    from wan import ops
+
+    L, H = 192, 2
+    q8 = ops.Q8Rows(L, H * 128, 128, DEV)
+    k8 = ops.Q8Rows(L, H * 128, 128, DEV, 64)
+    g = torch.Generator().manual_seed(4)
+    signs = (torch.randint(0, 2, (L, H * 128), generator=g) * 2 - 1).to(torch.int8)
+    k8.codes.copy_((signs * 127).to(DEV))
+    perm = torch.randperm(L, generator=g)
+    q8.codes.copy_((signs[perm] * 127).to(DEV))          # query i matches key perm[i]: dot = +2064512; others ~ N(0, 127^2 sqrt(128))
+    q8.scales[0].fill_(0.01)
+    k8.scales[0].fill_(0.02)
+    k8.scales[1].copy_(-12582912.0 * k8.scales[0])
+    v = torch.randn(L, H * 128, generator=g).to(torch.bfloat16).to(DEV)
+    out = ops.attention_qk8(q8, k8, v, H)
+    assert torch.equal(out.cpu(), v.cpu()[perm])
+
+
+def test_attention_qk8_close_to_bf16_attention_and_oracle_recipe():
+    """End to end against the reference recipe on fp32 inputs (quantisation inside the oracle): kernel vs oracle within the
+    bf16 P.V tolerance, and the quantisation itself costs < 2 % against unquantised attention on these inputs."""
+    from wan import ops
+
+    L, H = 700, 4
+    xq, xk = _rand(L, H, 7), _rand(L, H, 8)
+    v = _rand(L, H, 9, spread=False).to(torch.bfloat16)
+    w = torch.ones(H * 128)
+    qn, kn = wr.rms_norm(xq, w, 1e-6).view(L, H, 128), wr.rms_norm(xk, w, 1e-6).view(L, H, 128)
+    ref_q = wr.attention_qk_quant(qn, kn, v.float().view(L, H, 128)).reshape(L, H * 128)
+    ref_fp = wr.attention(qn, kn, v.float().view(L, H, 128)).reshape(L, H * 128)
+    q8 = ops.rmsnorm_rope_q8(xq.to(DEV), w.to(DEV), None, 128, False)
+    k8 = ops.rmsnorm_rope_q8(xk.to(DEV), w.to(DEV), None, 128, True)
+    out = ops.attention_qk8(q8, k8, v.to(DEV), H).float().cpu()
+    e_oracle = float((out - ref_q).norm() / ref_q.norm())
+    e_quant = float((ref_q - ref_fp).norm() / ref_fp.norm())
+    print(f"int8 Q.K^T: kernel vs recipe oracle {e_oracle:.2e}; recipe vs unquantised attention {e_quant:.2e}")
+    assert e_oracle < 1e-2 and e_quant < 2e-2
+
+
+def test_kernel_mode_block_with_quantized_qk_vs_oracle():
+    """attn.qk in the quant config: kernel-mode block (all linears W8A8 + int8 Q.K^T in self-attention) vs the simulation
+    oracle with the same recipe (BlockRef(qk_bits=8))."""
+    from test_gpu_block import make_block, rel_err
+    from wan import ops
+    from wan.quant_wanx_hip import WanAttentionBlockWithHipKernel, _FpSrc
+
+    dim, ffn, heads, grid, lc = 1536, 8960, 12, (2, 6, 8), 64
+    blk = make_block(dim, ffn, heads, 0)
+    sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    n_tok = grid[0] * grid[1] * grid[2]
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n_tok, dim, generator=g)
+    x[:, 5] *= 12.0
+    e0 = torch.randn(1, 6, dim, generator=g) * 0.3
+    ctx = torch.randn(lc, dim, generator=g)
+    freqs = wr.rope_freqs(dim // heads)
+    ref = wr.block_from_state(sd, heads, quant=True, qk_bits=8, cross_qk_bits=8)(x, e0, grid, n_tok, ctx, freqs)
+    ref_noqk = wr.block_from_state(sd, heads, quant=True)(x, e0, grid, n_tok, ctx, freqs)
+    hb = WanAttentionBlockWithHipKernel.from_float(blk.to(DEV), attn_qk8=True, cross_attn_qk8=True)
+    out = hb(x.to(DEV).clone(), e0.to(DEV), ops.rope_table(freqs, grid, DEV), n_tok, _FpSrc(ctx.to(DEV), torch.bfloat16)).float().cpu()
+    err = rel_err(out, ref)
+    print(f"block with int8 Q.K^T: rel err vs recipe oracle {err:.2e}; recipe vs FP-attention oracle {rel_err(ref, ref_noqk):.2e}")
+    assert err < 1e-2

@@ -40,11 +40,25 @@ struct AttnParams {
   int tiles_per_split;
   float* part_o;   // [splits, Lq, H*128] fp32: O^T accumulators relative to the split's reference maximum
   float* part_ml;  // [splits, Lq, H, 2]  fp32: (reference maximum m, row sum l)
+  // int8 Q.K^T (QK8): per-(token, head) symmetric int8 codes [tokens, H*128] and fp32 scale planes [H][stride]
+  const int8_t* q8;
+  const int8_t* k8;
+  int64_t q8_stride, k8_stride;   // bytes between consecutive tokens
+  const float* q_scale;           // delta_q[h][token]
+  const float* k_scale;           // delta_k[h][token], followed by the plane -12582912 * delta_k at + H * ks_stride
+  int64_t qs_stride, ks_stride;
 };
 
 constexpr int AT_D = 128, AT_QW = 32, AT_NW = 8, AT_QB = AT_QW * AT_NW, AT_KB = 64;
 constexpr int AT_TILE = AT_KB * AT_D * 2;  // 16 KiB per K or V tile
 constexpr int AT_STAGE = 2 * AT_TILE;
+// QK8 stage: int8 K tile (64 x 128 B) | bf16 V tile | 64 key scales | 64 dequantisation constants
+constexpr int AT_K8 = AT_KB * AT_D;               // 8 KiB
+constexpr int AT_SC8 = AT_K8 + AT_TILE;           // scales at 24 KiB
+constexpr int AT_STAGE8 = AT_SC8 + 2 * AT_KB * 4;  // 25088 B
+constexpr float AT_MAGIC = 12582912.0f;           // 1.5 * 2^23: int32 accumulators start at its bit pattern (see QK8 below)
+
+__device__ __forceinline__ int at_off8(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
 
 __device__ __forceinline__ int at_off(int row, int ch) {
   return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
@@ -63,27 +77,47 @@ __device__ unsigned long long g_stamp[8 * 16];
 #define STAMP(i)
 #endif
 
-template <bool DMA, bool SPLIT = false>
+// QK8 (int8 Q.K^T, the reference's q / k fake-quant recipe run on the integer matrix cores: Q/base/quant_attn.py:168-174,
+// W/models/quant_opensora.py:431-436): q and k arrive as per-(token, head) symmetric int8 codes with fp32 scales.
+//   S^T = K8 . Q8^T on v_mfma_i32_32x32x32_i8: 8 MFMAs per 64-key tile instead of 16, and the K tile is 8 KiB instead of 16.
+//   The int32 accumulators START at 0x4B400000, the bit pattern of 12582912.0f = 1.5 * 2^23: |dot| <= 128 * 127 * 127 < 2^22,
+//   so the accumulator's bits READ AS A FLOAT are exactly 12582912 + dot -- no int->float conversion -- and one fma per
+//   score, t = fma(f, delta_k, -12582912 * delta_k), applies the per-key scale (the constant comes precomputed beside the
+//   scale).  The per-query scale delta_q is folded into the exp2 coefficient.  P.V stays bf16.
+template <bool DMA, bool SPLIT = false, bool QK8 = false>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
+  static_assert(!QK8 || DMA, "the int8 Q.K^T form exists for the LDS-DMA pipeline only");
+  constexpr int STAGE = QK8 ? AT_STAGE8 : AT_STAGE;
+  constexpr int VOFF = QK8 ? AT_K8 : AT_TILE;  // byte offset of the V tile inside a stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int head = blockIdx.y;
   const int q0 = blockIdx.x * AT_QB + wave * AT_QW;
   const int nt = (p.Lk + AT_KB - 1) / AT_KB;
-  const float c = p.c;
+  float c = p.c;
   // key tiles of this workgroup: all of them, or one contiguous share under split-KV (the host makes every share non-empty)
   const int jt0 = SPLIT ? (int)blockIdx.z * p.tiles_per_split : 0;
   const int jt1 = SPLIT ? (jt0 + p.tiles_per_split < nt ? jt0 + p.tiles_per_split : nt) : nt;
 
   // ---- Q fragments: query (q0+fr), d = 16 s + 8 fh + [0,8)
-  bf16x8 qf[8];
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  typedef int v16i __attribute__((ext_vector_type(16)));
+  bf16x8 qf[QK8 ? 1 : 8];
+  v4i qf8[QK8 ? 4 : 1];  // QK8: query (q0+fr), d = 32 s + 16 fh + [0,16)
   {
     int qr = q0 + fr;
     if (qr >= p.Lq) qr = p.Lq - 1;
-    const uint16_t* qp = p.q + (int64_t)qr * p.q_stride + head * AT_D + 8 * fh;
+    if (QK8) {
+      const int8_t* qp = p.q8 + (int64_t)qr * p.q8_stride + head * AT_D + 16 * fh;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+      for (int s = 0; s < 4; ++s) qf8[s] = *reinterpret_cast<const v4i*>(qp + 32 * s);
+      c *= p.q_scale[(int64_t)head * p.qs_stride + qr];  // score = dot * delta_k * delta_q * softmax scale
+    } else {
+      const uint16_t* qp = p.q + (int64_t)qr * p.q_stride + head * AT_D + 8 * fh;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+    }
   }
 
   // ---- staging: thread handles 16-B chunks `tid` and `tid+512` of the 64x16-chunk K tile and V tile
@@ -139,8 +173,41 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     const int col_ = head * AT_D + ((((lane & 15) ^ (d_r << 2)) ^ (i)) << 3);                                   \
     __builtin_amdgcn_global_load_lds((glb_void*)((base) + (int64_t)kr_ * (stride) + col_), (lds_void*)(sK_ + (tilebyte) + 1024 * (i)), 16, 0, 0); \
   }
+  // QK8: the K tile is int8 (8 rows x 128 B per 1-KiB piece, 2 pieces per DMA wave: rows 16w + 8i + (lane>>3), physical chunk
+  // lane&7 holds logical chunk (lane&7) ^ ((row>>1)&7)); waves 4 and 5 fetch the tile's 64 key scales / constants.
+  const int d8_r = lane >> 3;
+#define AT_D8OFF(i) ((uint32_t)((16 * (wave & 3) + 8 * (i) + d8_r) * (int)p.k8_stride + head * AT_D + ((((lane & 7) ^ (((8 * (i) + d8_r) >> 1) & 7))) << 4)))
+  const uint32_t d8_k0 = QK8 ? AT_D8OFF(0) : 0, d8_k1 = QK8 ? AT_D8OFF(1) : 0;
+#undef AT_D8OFF
+#define AT_DMA8(j, stage)                                                                                       \
+  do {                                                                                                          \
+    char* st_ = smem + (stage) * STAGE;                                                                         \
+    if (dma_wave) {                                                                                             \
+      char* sK_ = st_ + (wave & 3) * 2048;                                                                      \
+      char* sV_ = st_ + (wave & 3) * 4096;                                                                      \
+      if (((j) + 1) * AT_KB <= p.Lk) {                                                                          \
+        const char* kt_ = reinterpret_cast<const char*>(p.k8) + (int64_t)(j) * AT_KB * p.k8_stride;             \
+        const char* vt_ = reinterpret_cast<const char*>(p.v) + (int64_t)(j) * (AT_KB * 2) * p.v_stride;         \
+        __builtin_amdgcn_global_load_lds((glb_void*)(kt_ + d8_k0), (lds_void*)(sK_), 16, 0, 0);                 \
+        __builtin_amdgcn_global_load_lds((glb_void*)(kt_ + d8_k1), (lds_void*)(sK_ + 1024), 16, 0, 0);          \
+        { char* sK_ = sV_; AT_DMA_F(vt_, d_v0, AT_K8, 0) AT_DMA_F(vt_, d_v1, AT_K8, 1) AT_DMA_F(vt_, d_v2, AT_K8, 2) AT_DMA_F(vt_, d_v3, AT_K8, 3) } \
+      } else {                                                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                      \
+          int kr_ = (j) * AT_KB + 16 * (wave & 3) + 8 * i_ + d8_r;                                              \
+          kr_ = kr_ < p.Lk ? kr_ : p.Lk - 1;                                                                    \
+          const int col_ = head * AT_D + ((((lane & 7) ^ (((8 * i_ + d8_r) >> 1) & 7))) << 4);                  \
+          __builtin_amdgcn_global_load_lds((glb_void*)(p.k8 + (int64_t)kr_ * p.k8_stride + col_), (lds_void*)(sK_ + 1024 * i_), 16, 0, 0); \
+        }                                                                                                       \
+        { char* sK_ = sV_; AT_DMA_S(p.v, p.v_stride, AT_K8, 0, j) AT_DMA_S(p.v, p.v_stride, AT_K8, 1, j) AT_DMA_S(p.v, p.v_stride, AT_K8, 2, j) AT_DMA_S(p.v, p.v_stride, AT_K8, 3, j) } \
+      }                                                                                                         \
+    } else if (wave < 6) { /* scale plane (wave 4) / constant plane (wave 5): 64 floats, one dword per lane */  \
+      const float* sp_ = p.k_scale + (int64_t)(wave - 4) * p.H * p.ks_stride + (int64_t)head * p.ks_stride + (int64_t)(j) * AT_KB + lane; \
+      __builtin_amdgcn_global_load_lds((glb_void*)sp_, (lds_void*)(st_ + AT_SC8 + (wave - 4) * 256), 4, 0, 0);  \
+    }                                                                                                           \
+  } while (0)
 #define AT_DMA(j, stage)                                                                                        \
   do {                                                                                                          \
+    if (QK8) { AT_DMA8(j, stage); break; }                                                                      \
     if (dma_wave) {                                                                                             \
       char* sK_ = smem + (stage) * AT_STAGE + (wave & 3) * 4096;                                                \
       if (((j) + 1) * AT_KB <= p.Lk) {                                                                          \
@@ -175,11 +242,19 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
+  // LDS-DMA instructions a wave issues per tile (= what may stay in flight behind a counted wait): 8 for the DMA waves of the
+  // bf16 form (waves 4-7 issue none: any count passes); QK8: 6 for waves 0-3 (2 K + 4 V pieces), 1 for waves 4-5 (scales)
+#define AT_WAIT_TILE_AHEAD()                                                                \
+  do {                                                                                      \
+    if (!QK8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                              \
+    else if (wave < 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                     \
+    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                                   \
+  } while (0)
   if (DMA) {
     AT_DMA(jt0, 0);
     if (jt0 + 1 < jt1) {
       AT_DMA(jt0 + 1, 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      AT_WAIT_TILE_AHEAD();
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -198,8 +273,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
   int st3 = 0;  // DMA: ring of three stages, (j - jt0) % 3
   for (int j = jt0; j < jt1; ++j) {
     const int cur = DMA ? st3 : (j & 1);
-    const char* sK = smem + cur * AT_STAGE;
-    const char* sV = sK + AT_TILE;
+    const char* sK = smem + cur * STAGE;
+    const char* sV = sK + VOFF;
     // every wave is past the barrier that ended tile j-1, so the stage that held it is free: tile j+2 goes there and has
     // two tile-times to land
     const int st_free = st3 == 0 ? 2 : st3 - 1;
@@ -210,7 +285,52 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     f32x16 s0, s1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-    if (DMA) {
+    if (QK8) {
+      v16i a0, a1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { a0[r] = 0x4B400000; a1[r] = 0x4B400000; }  // bits of 12582912.0f
+      v4i kf[4][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        kf[s][0] = *reinterpret_cast<const v4i*>(sK + at_off8(fr, 2 * s + fh));
+        kf[s][1] = *reinterpret_cast<const v4i*>(sK + at_off8(32 + fr, 2 * s + fh));
+      }
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      f32x4 sk0[4], sb0[4], sk1[4], sb1[4];  // key scales / constants of the two 32-key blocks, 4 consecutive keys each
+      {
+        const uint32_t sa = lds_base + cur * STAGE + AT_SC8 + 16 * fh;
+#define AT_SC(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(sa), "n"(off))
+        AT_SC(sk0[0], 0); AT_SC(sk0[1], 32); AT_SC(sk0[2], 64); AT_SC(sk0[3], 96);
+        AT_SC(sk1[0], 128); AT_SC(sk1[1], 160); AT_SC(sk1[2], 192); AT_SC(sk1[3], 224);
+        AT_SC(sb0[0], 256); AT_SC(sb0[1], 288); AT_SC(sb0[2], 320); AT_SC(sb0[3], 352);
+        AT_SC(sb1[0], 384); AT_SC(sb1[1], 416); AT_SC(sb1[2], 448); AT_SC(sb1[3], 480);
+#undef AT_SC
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (s + 2 < 4) {
+          kf[s + 2][0] = *reinterpret_cast<const v4i*>(sK + at_off8(fr, 2 * (s + 2) + fh));
+          kf[s + 2][1] = *reinterpret_cast<const v4i*>(sK + at_off8(32 + fr, 2 * (s + 2) + fh));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[s][0], qf8[s], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[s][1], qf8[s], a1, 0, 0, 0);
+      }
+      // t = dot * delta_k: register 4g+e holds key 8g + 4fh + e (+32 for the second block).  The 16 scale / constant reads
+      // are inline asm for the reason the V reads are (hipcc would put s_waitcnt vmcnt(0) in front of a plain LDS load
+      // while an LDS-DMA is in flight and drain the prefetch); they were issued ahead of the MFMAs above.
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(sk0[0]), "+v"(sk0[1]), "+v"(sk0[2]), "+v"(sk0[3]), "+v"(sb0[0]), "+v"(sb0[1]), "+v"(sb0[2]), "+v"(sb0[3]),
+                     "+v"(sk1[0]), "+v"(sk1[1]), "+v"(sk1[2]), "+v"(sk1[3]), "+v"(sb1[0]), "+v"(sb1[1]), "+v"(sb1[2]), "+v"(sb1[3]));
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s0[4 * g + e] = fmaf(__int_as_float(a0[4 * g + e]), sk0[g][e], sb0[g][e]);
+          s1[4 * g + e] = fmaf(__int_as_float(a1[4 * g + e]), sk1[g][e], sb1[g][e]);
+        }
+      }
+    } else if (DMA) {
       // K fragments run three d-slices ahead of the MFMAs that consume them
       bf16x8 kf[8][2];
 #pragma unroll
@@ -301,9 +421,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
       // whenever an LDS-DMA is in flight (it cannot tell the two stages apart), which would serialise the prefetch.
       // Reads of key slice ks+1 are issued before the MFMAs of slice ks; the counted lgkmcnt wait carries the eight
       // registers it publishes as operands so that the MFMAs cannot be scheduled above it.
-      const uint32_t vb = lds_base + cur * AT_STAGE;
+      const uint32_t vb = lds_base + cur * STAGE;
       s16x4 ta0, ta1, ta2, ta3, ta4, ta5, ta6, ta7, tb0, tb1, tb2, tb3, tb4, tb5, tb6, tb7;
-#define AT_TR(dst, areg, ks) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(vb + areg), "n"(AT_TILE + 4096 * (ks)))
+#define AT_TR(dst, areg, ks) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(vb + areg), "n"(VOFF + 4096 * (ks)))
 #define AT_TR8(P, ks)                                                                                      \
   AT_TR(P##0, va0, ks); AT_TR(P##1, va1, ks); AT_TR(P##2, va2, ks); AT_TR(P##3, va3, ks);                  \
   AT_TR(P##4, va4, ks); AT_TR(P##5, va5, ks); AT_TR(P##6, va6, ks); AT_TR(P##7, va7, ks)
@@ -347,7 +467,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     STAMP(3)
     if (DMA) {
       // tile j+1 must have landed; the eight instructions of tile j+2 (if issued; waves 4-7 issue none) may stay in flight
-      if (j + 2 < jt1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if (j + 2 < jt1) AT_WAIT_TILE_AHEAD();
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       st3 = st3 == 2 ? 0 : st3 + 1;
       STAMP(4)
@@ -376,7 +496,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
           *reinterpret_cast<float4*>(po + 32 * db + 8 * g) = make_float4(o[db][4 * g], o[db][4 * g + 1], o[db][4 * g + 2], o[db][4 * g + 3]);
       if (fh == 0) {
         float* pm = p.part_ml + (((int64_t)blockIdx.z * p.Lq + qr) * p.H + head) * 2;
-        pm[0] = m_run;
+        pm[0] = QK8 ? m_run * (c / p.c) : m_run;  // the merge kernel applies the global scale p.c: fold this query's delta_q in
         pm[1] = l_tot;
       }
     }
@@ -430,32 +550,59 @@ using namespace wanq;
 
 extern "C" int64_t wanq_attention_split_workspace(int64_t Lq, int heads, int head_dim, int splits);
 
+struct Qk8Args {  // int8 Q.K^T operands (NULL q8 = the bf16 form)
+  const int8_t* q8;
+  const int8_t* k8;
+  const float* q_scale;
+  const float* k_scale;
+  int64_t q8_stride, k8_stride, qs_stride, ks_stride;
+};
+
+template <bool SPLIT, bool QK8>
+static void launch_attn(const AttnParams& p, dim3 grid, hipStream_t st) {
+  constexpr int lds = 3 * (QK8 ? AT_STAGE8 : AT_STAGE);
+  static const bool attr_set = [] {  // once per instantiation, thread-safe
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true, SPLIT, QK8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    return true;
+  }();
+  (void)attr_set;
+  hipLaunchKernelGGL((attn_fwd_kernel<true, SPLIT, QK8>), grid, dim3(512), lds, st, p);
+}
+
 static int attention_impl(const void* q, const void* k, const void* v, void* o, int dtype, int64_t Lq, int64_t Lk, int heads,
                           int head_dim, int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride, float scale,
-                          int splits, void* workspace, int64_t workspace_bytes, void* stream) {
-  WANQ_REQUIRE(q && k && v && o, WANQ_E_ARG, "wanq_attention_fwd: NULL pointer");
-  WANQ_REQUIRE(dtype == WANQ_BF16, WANQ_E_ARG, "wanq_attention_fwd: only bf16 is implemented (dtype code %d)", dtype);
-  WANQ_REQUIRE(head_dim == AT_D, WANQ_E_SHAPE, "wanq_attention_fwd: head_dim=%d, only 128 is implemented", head_dim);
-  WANQ_REQUIRE(heads >= 1 && heads <= 65535, WANQ_E_SHAPE, "wanq_attention_fwd: heads=%d out of range", heads);
-  WANQ_REQUIRE(Lq >= 0 && Lk >= 1 && Lq < (1ll << 30) && Lk < (1ll << 30), WANQ_E_SHAPE, "wanq_attention_fwd: bad lengths");
+                          int splits, void* workspace, int64_t workspace_bytes, void* stream, const Qk8Args* q8 = nullptr) {
+  const char* what = q8 ? "wanq_attention_qk8_fwd" : "wanq_attention_fwd";
+  WANQ_REQUIRE((q8 || (q && k)) && v && o, WANQ_E_ARG, "%s: NULL pointer", what);
+  WANQ_REQUIRE(dtype == WANQ_BF16, WANQ_E_ARG, "%s: only bf16 is implemented (dtype code %d)", what, dtype);
+  WANQ_REQUIRE(head_dim == AT_D, WANQ_E_SHAPE, "%s: head_dim=%d, only 128 is implemented", what, head_dim);
+  WANQ_REQUIRE(heads >= 1 && heads <= 65535, WANQ_E_SHAPE, "%s: heads=%d out of range", what, heads);
+  WANQ_REQUIRE(Lq >= 0 && Lk >= 1 && Lq < (1ll << 30) && Lk < (1ll << 30), WANQ_E_SHAPE, "%s: bad lengths", what);
   const int64_t need = (int64_t)heads * head_dim;
-  WANQ_REQUIRE(q_stride >= need && k_stride >= need && v_stride >= need && o_stride >= need, WANQ_E_SHAPE,
-               "wanq_attention_fwd: token stride smaller than heads*head_dim");
-  WANQ_REQUIRE((q_stride | k_stride | v_stride | o_stride) % 8 == 0, WANQ_E_SHAPE, "wanq_attention_fwd: strides must be multiples of 8 elements");
-  WANQ_REQUIRE(k_stride < (1ll << 24) && v_stride < (1ll << 24), WANQ_E_SHAPE,
-               "wanq_attention_fwd: k / v token stride must be below 2^24 elements (32-bit lane offsets inside a 64-key tile)");
+  WANQ_REQUIRE(v_stride >= need && o_stride >= need && (q8 || (q_stride >= need && k_stride >= need)), WANQ_E_SHAPE,
+               "%s: token stride smaller than heads*head_dim", what);
+  WANQ_REQUIRE((v_stride | o_stride) % 8 == 0 && (q8 || (q_stride | k_stride) % 8 == 0), WANQ_E_SHAPE,
+               "%s: strides must be multiples of 8 elements", what);
+  WANQ_REQUIRE(v_stride < (1ll << 24) && (q8 || k_stride < (1ll << 24)), WANQ_E_SHAPE,
+               "%s: k / v token stride must be below 2^24 elements (32-bit lane offsets inside a 64-key tile)", what);
+  if (q8) {
+    WANQ_REQUIRE(q8->q8 && q8->k8 && q8->q_scale && q8->k_scale, WANQ_E_ARG, "%s: NULL pointer", what);
+    WANQ_REQUIRE(q8->q8_stride >= need && q8->k8_stride >= need && q8->q8_stride % 16 == 0 && q8->k8_stride % 16 == 0 &&
+                     q8->k8_stride < (1ll << 24),
+                 WANQ_E_SHAPE, "%s: int8 token strides must be multiples of 16 bytes, >= heads*128 and below 2^24", what);
+    WANQ_REQUIRE(q8->qs_stride >= Lq && q8->ks_stride >= ((Lk + AT_KB - 1) / AT_KB) * AT_KB, WANQ_E_SHAPE,
+                 "%s: scale planes are [heads][stride] with q stride >= Lq and k stride >= Lk rounded up to 64", what);
+  }
   if (Lq == 0) return WANQ_OK;
   AttnParams p{(const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (uint16_t*)o, q_stride, k_stride, v_stride, o_stride,
                (int)Lq, (int)Lk, heads, scale * 1.4426950408889634f};
+  if (q8) {
+    p.q8 = q8->q8; p.k8 = q8->k8; p.q_scale = q8->q_scale; p.k_scale = q8->k_scale;
+    p.q8_stride = q8->q8_stride; p.k8_stride = q8->k8_stride; p.qs_stride = q8->qs_stride; p.ks_stride = q8->ks_stride;
+  }
   // Default: LDS-DMA staging into a three-stage ring (96 KiB).  WANQ_ATTN_V1=1 selects the register-staged two-stage form
   // (64 KiB) kept for A/B timing.
   static const bool v1 = [] { const char* e = getenv("WANQ_ATTN_V1"); return e && e[0] == '1'; }();
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_STAGE);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * AT_STAGE);
-    attr_set = true;
-  }
   dim3 grid((unsigned)((Lq + AT_QB - 1) / AT_QB), (unsigned)heads);
   const int nt = (int)((Lk + AT_KB - 1) / AT_KB);
   if (splits > nt) splits = nt;
@@ -463,9 +610,20 @@ static int attention_impl(const void* q, const void* k, const void* v, void* o, 
     p.tiles_per_split = (nt + splits - 1) / splits;
     splits = (nt + p.tiles_per_split - 1) / p.tiles_per_split;  // no empty share
   }
+  hipStream_t st = (hipStream_t)stream;
   if (splits <= 1) {
-    if (v1) hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(512), 2 * AT_STAGE, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(512), 3 * AT_STAGE, (hipStream_t)stream, p);
+    if (q8) {
+      launch_attn<false, true>(p, grid, st);
+    } else if (v1) {
+      static const bool attr_v1 = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_STAGE);
+        return true;
+      }();
+      (void)attr_v1;
+      hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(512), 2 * AT_STAGE, st, p);
+    } else {
+      launch_attn<false, false>(p, grid, st);
+    }
 #ifdef WANQ_ATTN_STAMP
     {
       (void)hipStreamSynchronize((hipStream_t)stream);
@@ -477,24 +635,20 @@ static int attention_impl(const void* q, const void* k, const void* v, void* o, 
         printf("[stamp] %-10s %8.1f %8.1f %8.1f %8.1f\n", names[i], (double)h[0 * 16 + i] / nt, (double)h[3 * 16 + i] / nt, (double)h[4 * 16 + i] / nt, (double)h[7 * 16 + i] / nt);
     }
 #endif
-    return check_launch("wanq_attention_fwd");
+    return check_launch(what);
   }
   const int64_t need_ws = wanq_attention_split_workspace(Lq, heads, head_dim, splits);
   WANQ_REQUIRE(workspace && workspace_bytes >= need_ws, WANQ_E_ARG,
-               "wanq_attention_fwd_split: workspace of %lld bytes needed, %lld given", (long long)need_ws, (long long)workspace_bytes);
-  WANQ_REQUIRE(((uintptr_t)workspace & 15) == 0, WANQ_E_ARG, "wanq_attention_fwd_split: workspace must be 16-byte aligned");
+               "%s: split-KV workspace of %lld bytes needed, %lld given", what, (long long)need_ws, (long long)workspace_bytes);
+  WANQ_REQUIRE(((uintptr_t)workspace & 15) == 0, WANQ_E_ARG, "%s: workspace must be 16-byte aligned", what);
   p.part_o = static_cast<float*>(workspace);
   p.part_ml = p.part_o + (int64_t)splits * Lq * heads * AT_D;
-  static bool attr_split = false;
-  if (!attr_split) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * AT_STAGE);
-    attr_split = true;
-  }
   grid.z = (unsigned)splits;
-  hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, dim3(512), 3 * AT_STAGE, (hipStream_t)stream, p);
+  if (q8) launch_attn<true, true>(p, grid, st);
+  else launch_attn<true, false>(p, grid, st);
   const int64_t threads = Lq * heads * (AT_D / 4);
-  hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, splits);
-  return check_launch("wanq_attention_fwd_split");
+  hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p, splits);
+  return check_launch(what);
 }
 
 extern "C" int64_t wanq_attention_split_workspace(int64_t Lq, int heads, int head_dim, int splits) {
@@ -515,4 +669,15 @@ extern "C" int wanq_attention_fwd_split(const void* q, const void* k, const void
   WANQ_REQUIRE(splits >= 1 && splits <= 64, WANQ_E_ARG, "wanq_attention_fwd_split: splits=%d must be 1..64", splits);
   return attention_impl(q, k, v, o, dtype, Lq, Lk, heads, head_dim, q_stride, k_stride, v_stride, o_stride, scale, splits, workspace,
                         workspace_bytes, stream);
+}
+
+extern "C" int wanq_attention_qk8_fwd(const int8_t* q8, const float* q_scale, int64_t qs_stride, const int8_t* k8,
+                                      const float* k_scale, int64_t ks_stride, const void* v, void* o, int dtype, int64_t Lq,
+                                      int64_t Lk, int heads, int head_dim, int64_t q8_stride, int64_t k8_stride,
+                                      int64_t v_stride, int64_t o_stride, float scale, int splits, void* workspace,
+                                      int64_t workspace_bytes, void* stream) {
+  WANQ_REQUIRE(splits >= 1 && splits <= 64, WANQ_E_ARG, "wanq_attention_qk8_fwd: splits=%d must be 1..64", splits);
+  const Qk8Args a{q8, k8, q_scale, k_scale, q8_stride, k8_stride, qs_stride, ks_stride};
+  return attention_impl(nullptr, nullptr, v, o, dtype, Lq, Lk, heads, head_dim, 0, 0, v_stride, o_stride, scale, splits, workspace,
+                        workspace_bytes, stream, &a);
 }

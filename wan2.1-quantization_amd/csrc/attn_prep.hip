@@ -18,6 +18,13 @@ struct PrepParams {
   int64_t rows, rows_per_batch, positions;
   int cols, head_dim;
   float eps;
+  // optional int8 form for the int8 Q.K^T attention (wanq_attention_qk8_fwd): per-(token, head) symmetric 8-bit codes of the
+  // normalised + rotated row (DynamicQuantizer semantics on [tokens*heads, head_dim] rows, Q/base/quant_attn.py:168-174 /
+  // W/models/quant_opensora.py:431-436) and two fp32 planes [heads][scale_stride]: delta, and -12582912 * delta (the
+  // constant the attention kernel's dequantising fma takes, see attention.hip)
+  int8_t* q8;
+  float* qscale;
+  int64_t scale_stride;
 };
 
 __device__ __forceinline__ void prep_load8(const void* base, int dt, int64_t elem, float (&v)[8]) {
@@ -84,7 +91,26 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const PrepParams p) {
         v[i][2 * k + 1] = a * cs[2 * k + 1] + b * cs[2 * k];
       }
     }
-    prep_store8(p.out, p.out_dtype, rbase + c0, v[i]);
+    if (p.out) prep_store8(p.out, p.out_dtype, rbase + c0, v[i]);
+    if (p.q8) {  // head_dim == 128: a head is the 16 chunks of 16 consecutive lanes
+      float m = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[i][j]));
+#define PREP_XMAX(o) m = fmaxf(m, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(m), ((o) << 10) | 0x1f)))
+      PREP_XMAX(1); PREP_XMAX(2); PREP_XMAX(4); PREP_XMAX(8);  // lane ^ o inside the head's 16 lanes
+#undef PREP_XMAX
+      float scale = m / 127.0f;
+      if (scale < 1e-6f) scale = 1e-6f;  // qdiff eps rule (base_quantizer.py:122-127)
+      int qi[8];
+      quant8_div_rne(v[i], scale, 1.0f / scale, qi);
+      *reinterpret_cast<uint2*>(p.q8 + rbase + c0) =
+          make_uint2(pack4_i8_fast(qi[0], qi[1], qi[2], qi[3]), pack4_i8_fast(qi[4], qi[5], qi[6], qi[7]));
+      if ((lane & 15) == 0) {
+        const int64_t so = (int64_t)(c0 >> 7) * p.scale_stride + row;
+        p.qscale[so] = scale;
+        p.qscale[(int64_t)(C >> 7) * p.scale_stride + so] = -12582912.0f * scale;
+      }
+    }
   }
 }
 
@@ -92,18 +118,21 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const PrepParams p) {
 
 using namespace wanq;
 
-extern "C" int wanq_rmsnorm_rope(const void* x, int x_dtype, const float* weight, const float* rope, void* out,
-                                 int out_dtype, int64_t rows, int cols, int head_dim, int64_t rows_per_batch,
-                                 int64_t positions, float eps, void* stream) {
-  WANQ_REQUIRE(x && out, WANQ_E_ARG, "wanq_rmsnorm_rope: NULL pointer");
-  WANQ_REQUIRE(is_fp(x_dtype) && is_fp(out_dtype), WANQ_E_ARG, "wanq_rmsnorm_rope: bad dtype code");
+static int rmsnorm_rope_impl(const void* x, int x_dtype, const float* weight, const float* rope, void* out, int out_dtype,
+                             int8_t* q8, float* qscale, int64_t scale_stride, int64_t rows, int cols, int head_dim,
+                             int64_t rows_per_batch, int64_t positions, float eps, void* stream) {
+  WANQ_REQUIRE(x && (out || q8), WANQ_E_ARG, "wanq_rmsnorm_rope: NULL pointer");
+  WANQ_REQUIRE(!q8 || (qscale && head_dim == 128 && cols % 128 == 0 && scale_stride >= rows), WANQ_E_ARG,
+               "wanq_rmsnorm_rope_q8: needs qscale, head_dim == 128, cols %% 128 == 0 and scale_stride >= rows");
+  WANQ_REQUIRE(is_fp(x_dtype) && (!out || is_fp(out_dtype)), WANQ_E_ARG, "wanq_rmsnorm_rope: bad dtype code");
   WANQ_REQUIRE(weight || rope, WANQ_E_ARG, "wanq_rmsnorm_rope: nothing to do (weight and rope both NULL)");
   WANQ_REQUIRE(cols >= 8 && cols % 8 == 0 && cols <= 16384, WANQ_E_SHAPE, "wanq_rmsnorm_rope: cols=%d must be a multiple of 8 in [8,16384]", cols);
   WANQ_REQUIRE(!rope || (head_dim >= 8 && head_dim % 8 == 0 && cols % head_dim == 0), WANQ_E_SHAPE,
                "wanq_rmsnorm_rope: head_dim=%d must be a multiple of 8 dividing cols=%d", head_dim, cols);
   WANQ_REQUIRE(rows >= 0 && rows < (1ll << 31) && rows_per_batch >= 1, WANQ_E_SHAPE, "wanq_rmsnorm_rope: bad rows");
   if (rows == 0) return WANQ_OK;
-  PrepParams p{x, out, weight, rope, x_dtype, out_dtype, rows, rows_per_batch, positions, cols, head_dim > 0 ? head_dim : 8, eps};
+  PrepParams p{x, out, weight, rope, x_dtype, out_dtype, rows, rows_per_batch, positions, cols, head_dim > 0 ? head_dim : 8, eps,
+               q8, qscale, scale_stride};
   hipStream_t st = (hipStream_t)stream;
   const int chunks = cols / 8;
 #define WANQ_PR(WPR, NCH) \
@@ -119,4 +148,20 @@ extern "C" int wanq_rmsnorm_rope(const void* x, int x_dtype, const float* weight
   else WANQ_PR(4, 8);
 #undef WANQ_PR
   return check_launch("wanq_rmsnorm_rope");
+}
+
+extern "C" int wanq_rmsnorm_rope(const void* x, int x_dtype, const float* weight, const float* rope, void* out,
+                                 int out_dtype, int64_t rows, int cols, int head_dim, int64_t rows_per_batch,
+                                 int64_t positions, float eps, void* stream) {
+  WANQ_REQUIRE(out, WANQ_E_ARG, "wanq_rmsnorm_rope: NULL pointer");
+  return rmsnorm_rope_impl(x, x_dtype, weight, rope, out, out_dtype, nullptr, nullptr, 0, rows, cols, head_dim, rows_per_batch,
+                           positions, eps, stream);
+}
+
+extern "C" int wanq_rmsnorm_rope_q8(const void* x, int x_dtype, const float* weight, const float* rope, void* out,
+                                    int out_dtype, int8_t* q8, float* qscale, int64_t scale_stride, int64_t rows, int cols,
+                                    int head_dim, int64_t rows_per_batch, int64_t positions, float eps, void* stream) {
+  WANQ_REQUIRE(q8, WANQ_E_ARG, "wanq_rmsnorm_rope_q8: q8 is required");
+  return rmsnorm_rope_impl(x, x_dtype, weight, rope, out, out_dtype, q8, qscale, scale_stride, rows, cols, head_dim,
+                           rows_per_batch, positions, eps, stream);
 }

@@ -29,6 +29,73 @@ def rmsnorm_rope_(x, weight, rope, head_dim, rows_per_batch=None, eps=1e-6, out=
     return out
 
 
+class Q8Rows:
+    """Per-(token, head) int8 form of a q or k tensor for the int8 Q.K^T attention: codes int8 [rows, C] and the fp32 scale
+    planes [2, H, stride] (delta, -12582912 * delta) that wanq_rmsnorm_rope_q8 writes."""
+
+    def __init__(self, rows, cols, head_dim, device, pad_to=1):
+        self.rows, self.cols, self.heads = rows, cols, cols // head_dim
+        self.stride = -(-rows // pad_to) * pad_to
+        self.codes = torch.empty(rows, cols, dtype=torch.int8, device=device)
+        self.scales = torch.zeros(2, self.heads, self.stride, dtype=torch.float32, device=device)
+
+
+def rmsnorm_rope_q8(x, weight, rope, head_dim, for_keys, eps=1e-6, want_fp=False):
+    """RMSNorm_C(x) * weight -> rotary -> per-(token, head) int8 quantise: returns Q8Rows (and the bf16 row when want_fp).
+    for_keys: pad the scale planes' row stride to a multiple of 64 (the attention kernel fetches key scales per 64-key tile)."""
+    _C.check_gpu("x", x)
+    _C.check_contig("x", x)
+    rows, cols = x.shape
+    if head_dim != 128:
+        raise RuntimeError("the int8 Q.K^T attention is implemented for head_dim 128")
+    positions = 0
+    if rope is not None:
+        _C.check_dtype("rope", rope, torch.float32)
+        _C.check_contig("rope", rope)
+        positions = rope.shape[0]
+    if weight is not None:
+        _C.check_dtype("weight", weight, torch.float32)
+        _C.check_shape("weight", weight, cols)
+    q8 = Q8Rows(rows, cols, head_dim, x.device, 64 if for_keys else 1)
+    out = torch.empty(rows, cols, dtype=torch.bfloat16, device=x.device) if want_fp else None
+    with torch.cuda.device(x.device):
+        _C.call("wanq_rmsnorm_rope_q8", _C.ptr(x), _C.dt(x), _C.ptr(weight), _C.ptr(rope), _C.ptr(out),
+                _C.BF16, _C.ptr(q8.codes), _C.ptr(q8.scales), q8.stride, rows, cols, head_dim, rows, positions, float(eps),
+                _C.stream())
+    return (q8, out) if want_fp else q8
+
+
+def attention_qk8(q8, k8, v, num_heads, k_len=None, out=None, splits=None):
+    """softmax((q8 . k8) * delta_q * delta_k / sqrt(d)) v with the score matrix on the int8 matrix cores
+    (csrc/attention.hip, QK8); q8 / k8: Q8Rows, v bf16 [Lk, C] -> bf16 [Lq, C]."""
+    Lq, C = q8.codes.shape
+    d = C // num_heads
+    _C.check_gpu("v", v)
+    _C.check_dtype("v", v, torch.bfloat16)
+    if v.dim() != 2 or v.shape[1] != C or v.stride(1) != 1 or v.shape[0] != k8.codes.shape[0]:
+        raise RuntimeError(f"Tensor v must be [{k8.codes.shape[0]}, {C}] with unit column stride")
+    Lk = k8.codes.shape[0] if k_len is None else min(int(k_len), k8.codes.shape[0])
+    if out is None:
+        out = torch.empty(Lq, C, dtype=torch.bfloat16, device=v.device)
+    if splits is None:
+        splits = attention_splits(Lq, Lk, num_heads, v.device)
+    ws, nbytes = None, 0
+    if splits > 1:
+        nbytes = _C.lib.wanq_attention_split_workspace(Lq, num_heads, d, int(splits))
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=v.device)
+    with torch.cuda.device(v.device):
+        if _attn_timer is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        _C.call("wanq_attention_qk8_fwd", _C.ptr(q8.codes), _C.ptr(q8.scales), q8.stride, _C.ptr(k8.codes), _C.ptr(k8.scales),
+                k8.stride, _C.ptr(v), _C.ptr(out), _C.BF16, Lq, Lk, num_heads, d, q8.codes.stride(0), k8.codes.stride(0),
+                v.stride(0), out.stride(0), 1.0 / math.sqrt(d), max(1, int(splits)), _C.ptr(ws), nbytes, _C.stream())
+        if _attn_timer is not None:
+            ev1.record()
+            _attn_timer.append((ev0, ev1, 4 * Lq * Lk * d * num_heads))
+    return out
+
+
 def rope_table(freqs, grid, device):
     """(cos, sin) table fp32 [f*h*w, d/2, 2] for one (f,h,w) grid from the model's complex freqs [1024, d/2]
     -- the `freqs_i` of rope_apply (wan/modules/model.py:56-61), built once per grid in float64."""
@@ -107,16 +174,3 @@ def attention(q, k, v, num_heads, k_len=None, out=None, splits=None):
             ev1.record()
             _attn_timer.append((ev0, ev1, 4 * Lq * Lk * d * num_heads))
     return out
-
-
-def attention_sdpa(q, k, v, num_heads, k_len=None):
-    """The same contraction through torch SDPA -- kept ONLY as a timing reference for tools/microbench.py."""
-    Lq, C = q.shape
-    d = C // num_heads
-    if k_len is not None and k_len < k.shape[0]:
-        k, v = k[:k_len], v[:k_len]
-    qh = q.view(1, Lq, num_heads, d).transpose(1, 2)
-    kh = k.view(1, k.shape[0], num_heads, d).transpose(1, 2)
-    vh = v.view(1, v.shape[0], num_heads, d).transpose(1, 2)
-    o = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh, scale=1.0 / math.sqrt(d))
-    return o.transpose(1, 2).reshape(Lq, C)

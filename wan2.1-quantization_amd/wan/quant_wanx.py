@@ -113,7 +113,16 @@ class QuantWanModel(WanModel, QuantModel):
         reference does with `int_weight.pt`: codes, scales, zero points, biases and activation pre-multipliers of every
         quantized Linear come from the file (either format of quantize_and_save_weight), a quantized Linear without its keys
         or with a shape mismatch is an error, and the number of tensors taken is logged."""
-        self.hip_blocks = nn.ModuleList([WanAttentionBlockWithHipKernel.from_float(b, None, False, act_dtype) for b in self.blocks])
+        qk8 = {}
+        for key in ("attn", "cross_attn"):  # quant_config.attn.qk / cross_attn.qk (Q/base/quant_attn.py:19-29,130-143)
+            sub = self.q_cfg.get(key, None) if self.q_cfg is not None else None
+            qk = sub.get("qk", None) if sub is not None else None
+            if qk is not None:
+                if qk.get("n_bits", 8) != 8 or not qk.get("sym", True):
+                    raise NotImplementedError(f"{key}.qk: the int8 Q.K^T kernel implements symmetric 8-bit q / k")
+                qk8[key] = True
+        self.hip_blocks = nn.ModuleList([WanAttentionBlockWithHipKernel.from_float(
+            b, None, False, act_dtype, attn_qk8=qk8.get("attn", False), cross_attn_qk8=qk8.get("cross_attn", False)) for b in self.blocks])
         if load_path:
             sd = torch.load(load_path, map_location="cpu", weights_only=True)
             taken = 0

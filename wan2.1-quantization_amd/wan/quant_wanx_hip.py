@@ -254,10 +254,13 @@ class _Attn(nn.Module):
 
 
 class WanAttentionBlockWithHipKernel(nn.Module):
-    def __init__(self, dim, ffn_dim, num_heads, eps=1e-6, act_dtype=torch.bfloat16):
+    def __init__(self, dim, ffn_dim, num_heads, eps=1e-6, act_dtype=torch.bfloat16, attn_qk8=False, cross_attn_qk8=False):
         super().__init__()
         self.dim, self.ffn_dim, self.num_heads, self.head_dim, self.eps = dim, ffn_dim, num_heads, dim // num_heads, eps
         self.act_dtype = act_dtype
+        # quant_config.attn.qk / cross_attn.qk (8-bit symmetric): q and k of that attention leave RMSNorm + RoPE as
+        # per-(token, head) int8 codes and Q.K^T runs on the int8 matrix cores (Q/base/quant_attn.py:168-174)
+        self.attn_qk8, self.cross_attn_qk8 = bool(attn_qk8), bool(cross_attn_qk8)
         self.self_attn, self.cross_attn = _Attn(dim), _Attn(dim)
         self.ffn0 = self.ffn2 = None
         self.register_buffer("modulation", torch.zeros(1, 6, dim))
@@ -266,11 +269,11 @@ class WanAttentionBlockWithHipKernel(nn.Module):
         self.register_buffer("ones_gate", torch.ones(dim))
 
     @classmethod
-    def from_float(cls, blk, n_bits=8, sym=False, act_dtype=torch.bfloat16):
+    def from_float(cls, blk, n_bits=8, sym=False, act_dtype=torch.bfloat16, attn_qk8=False, cross_attn_qk8=False):
         """Build from a WanAttentionBlock (wan/modules/model.py) whose Linears are either plain nn.Linear
         (quantized here with plain per-channel W8 when n_bits is given, kept FP when n_bits is None) or qdiff
         QuantizedLinear variants (their codes / parameters / ViDiT transform are taken over as they are)."""
-        m = cls(blk.dim, blk.ffn_dim, blk.num_heads, blk.eps, act_dtype).to(blk.modulation.device)
+        m = cls(blk.dim, blk.ffn_dim, blk.num_heads, blk.eps, act_dtype, attn_qk8, cross_attn_qk8).to(blk.modulation.device)
         for name in ("self_attn", "cross_attn"):
             src, dst = getattr(blk, name), getattr(m, name)
             for l in "qkvo":
@@ -321,13 +324,20 @@ class WanAttentionBlockWithHipKernel(nn.Module):
         h = _LnSrc(self, x, None, e[:, 0], e[:, 1])
         h.prefetch([sa.q, sa.k, sa.v])  # one pass over x for the three ViDiT-transformed int8 inputs
         q = self._linear(sa.q, h)
-        ops.rmsnorm_rope_(q, sa.norm_q_weight, rope, d, eps=self.eps)
-        if sp is None or sp.size == 1:
+        if self.attn_qk8 and (sp is None or sp.size == 1):
+            # (under sequence parallelism the exchange moves bf16 q / k; the int8 form is single-rank for now)
+            q8 = ops.rmsnorm_rope_q8(q, sa.norm_q_weight, rope, d, False, eps=self.eps)
+            k8 = ops.rmsnorm_rope_q8(self._linear(sa.k, h), sa.norm_k_weight, rope, d, True, eps=self.eps)
+            v = self._linear(sa.v, h)
+            o = ops.attention_qk8(q8, k8, v, H, seq_len)
+        elif sp is None or sp.size == 1:
+            ops.rmsnorm_rope_(q, sa.norm_q_weight, rope, d, eps=self.eps)
             k = self._linear(sa.k, h)
             ops.rmsnorm_rope_(k, sa.norm_k_weight, rope, d, eps=self.eps)
             v = self._linear(sa.v, h)
             o = ops.attention(q, k, v, H, seq_len)
         else:
+            ops.rmsnorm_rope_(q, sa.norm_q_weight, rope, d, eps=self.eps)
             # Ulysses, pipelined over head chunks: this rank's H/P heads are split in two; the exchange of chunk 1 (and the
             # way back of chunk 0) flies under the attention of the other chunk, so about half of the all-to-all time of a
             # block hides behind its 2-6 ms of attention.  The collectives run in issue order on the group's own stream.
@@ -352,11 +362,15 @@ class WanAttentionBlockWithHipKernel(nn.Module):
         # ---- cross attention: LN_affine -> q; k,v from the text context
         h = _LnSrc(self, x, self.norm3_weight, self.norm3_bias.view(1, -1), None)
         q = self._linear(ca.q, h)
-        ops.rmsnorm_rope_(q, ca.norm_q_weight, None, d, eps=self.eps)
         k = self._linear(ca.k, ctx)
-        ops.rmsnorm_rope_(k, ca.norm_k_weight, None, d, eps=self.eps)
         v = self._linear(ca.v, ctx)
-        o = ops.attention(q, k, v, H)
+        if self.cross_attn_qk8:
+            o = ops.attention_qk8(ops.rmsnorm_rope_q8(q, ca.norm_q_weight, None, d, False, eps=self.eps),
+                                  ops.rmsnorm_rope_q8(k, ca.norm_k_weight, None, d, True, eps=self.eps), v, H)
+        else:
+            ops.rmsnorm_rope_(q, ca.norm_q_weight, None, d, eps=self.eps)
+            ops.rmsnorm_rope_(k, ca.norm_k_weight, None, d, eps=self.eps)
+            o = ops.attention(q, k, v, H)
         self._linear(ca.o, _FpSrc(o), gate=self.ones_gate, residual=x)
 
         # ---- FFN: LN*(1+e4)+e3 -> GEMM+GELU -> GEMM (+gate, +residual)
@@ -364,52 +378,3 @@ class WanAttentionBlockWithHipKernel(nn.Module):
         hid = self._linear(self.ffn0, h, gelu=True)
         self._linear(self.ffn2, _FpSrc(hid), gate=e[0, 5].contiguous(), residual=x)
         return x
-
-
-class QuantWanModelHip(nn.Module):
-    """Kernel-mode model: FP embedders / head of a WanModel + WanAttentionBlockWithHipKernel blocks.
-    forward has WanModel.forward's signature (batch of ONE sample, as every T2V call site uses it)."""
-
-    def __init__(self, fp_model: WanModel, n_bits=8, sym=False, act_dtype=torch.bfloat16, keep_fp_blocks=False):
-        super().__init__()
-        self.cfg = dict(fp_model.config)
-        self.fp = fp_model  # embedders + head are used as they are (FP, remain_fp_regex: config.yaml:8)
-        self.blocks = nn.ModuleList()
-        for i, blk in enumerate(fp_model.blocks):
-            self.blocks.append(WanAttentionBlockWithHipKernel.from_float(blk, n_bits, sym, act_dtype))
-        # the FP blocks are detached from the FP model (its forward is only used for embed/head); they are kept
-        # on request as the FP reference for quality metrics
-        self.fp_blocks = fp_model.blocks if keep_fp_blocks else None
-        fp_model.blocks = nn.ModuleList()
-        if not keep_fp_blocks:
-            torch.cuda.empty_cache()
-        self._rope_cache = {}
-
-    def _rope(self, grid, device):
-        if grid not in self._rope_cache:
-            self._rope_cache[grid] = ops.rope_table(self.fp.freqs, grid, device)
-        return self._rope_cache[grid]
-
-    @torch.no_grad()
-    def forward(self, x, t, context, seq_len, sp=None):
-        """WanModel.forward signature for ONE sample; with `sp` (SeqParallel) the token sequence is sharded
-        over the group as usp_dit_forward does (xdit_context_parallel.py:131-142): seq_len must be a multiple
-        of sp.size (WanT2V.generate pads it so, text2video.py:170-172)."""
-        assert len(x) == 1, "kernel-mode forward takes one sample (cond and uncond are separate passes)"
-        with torch.autocast("cuda", enabled=False):
-            h, e, e0, ctx, seq_lens, grids = self.fp.embed(x, t, context, seq_len)
-            h = h[0].float()  # [seq_len, C] fp32 residual stream
-            rope = self._rope(grids[0], h.device)
-            if sp is not None and sp.size > 1:
-                assert seq_len % sp.size == 0
-                lp = seq_len // sp.size
-                h = sp.shard_rows(h)
-                rope = rope[sp.rank * lp:(sp.rank + 1) * lp]  # may be shorter than lp on the last rank: pads stay unrotated
-            h = h.contiguous()
-            cq = _FpSrc(ctx[0].float().contiguous(), self.blocks[0].act_dtype)
-            for blk in self.blocks:
-                blk(h, e0.float(), rope, seq_lens[0], cq, sp)
-            out = self.fp.head(h.unsqueeze(0), e)
-            if sp is not None and sp.size > 1:
-                out = sp.all_gather_rows(out[0]).unsqueeze(0)
-            return [u.float() for u in self.fp.unpatchify(out, grids)]
