@@ -117,6 +117,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
       const uint16_t* qp = p.q + (int64_t)qr * p.q_stride + head * AT_D + 8 * fh;
 #pragma unroll
       for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+      // fold softmax scale * log2(e) into Q once: the accumulators then ARE exp2 arguments (minus the running maximum, which
+      // rides in as the MFMA chain's initial accumulator, below) and the per-score fma of the usual form disappears
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[s][e] = (__bf16)((float)qf[s][e] * c);
     }
   }
 
@@ -161,8 +167,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
   // vector arithmetic: `base + zero-extended 32-bit lane offset` is the instruction's own sgpr + vgpr addressing.  (The
   // 64-bit `row * stride` per lane and instruction it replaces cost ~20 quarter-rate integer multiplies per tile and
   // wave.)  Only a ragged last tile clamps rows, on the slow path.
-  const uint32_t d_k0 = AT_DOFF(p.k_stride, 0), d_k1 = AT_DOFF(p.k_stride, 1), d_k2 = AT_DOFF(p.k_stride, 2), d_k3 = AT_DOFF(p.k_stride, 3);
-  const uint32_t d_v0 = AT_DOFF(p.v_stride, 0), d_v1 = AT_DOFF(p.v_stride, 1), d_v2 = AT_DOFF(p.v_stride, 2), d_v3 = AT_DOFF(p.v_stride, 3);
+  uint32_t d_k0 = AT_DOFF(p.k_stride, 0), d_k1 = AT_DOFF(p.k_stride, 1), d_k2 = AT_DOFF(p.k_stride, 2), d_k3 = AT_DOFF(p.k_stride, 3);
+  uint32_t d_v0 = AT_DOFF(p.v_stride, 0), d_v1 = AT_DOFF(p.v_stride, 1), d_v2 = AT_DOFF(p.v_stride, 2), d_v3 = AT_DOFF(p.v_stride, 3);
 #undef AT_DOFF
 #define AT_DMA_F(base, off, tilebyte, i) \
   __builtin_amdgcn_global_load_lds((glb_void*)((base) + (off)), (lds_void*)(sK_ + (tilebyte) + 1024 * (i)), 16, 0, 0);
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = QK8 ? -INFINITY : 0.f, l_run = 0.f;
 
   // LDS-DMA instructions a wave issues per tile (= what may stay in flight behind a counted wait): 8 for the DMA waves of the
   // bf16 form (waves 4-7 issue none: any count passes); QK8: 6 for waves 0-3 (2 K + 4 V pieces), 1 for waves 4-5 (scales)
@@ -270,14 +276,32 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
   unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_) :: "memory");
 #endif
-  int st3 = 0;  // DMA: ring of three stages, (j - jt0) % 3
-  for (int j = jt0; j < jt1; ++j) {
-    const int cur = DMA ? st3 : (j & 1);
+  // bf16 form: -m_run (log2 domain) in all 16 registers: the initial accumulator of both S chains, rewritten only when the
+  // running maximum moves (the first tile and lazy-rescale events)
+  f32x16 sinit;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sinit[r] = 0.f;
+  // The ring position (j - jt0) % 3 is made a compile-time constant by unrolling the tile loop over the three stages (two for
+  // the register-staged form): every LDS address of a tile is then `per-lane constant + immediate`, which takes ~25 address
+  // VALU instructions per tile out of the loop.
+  // (The split-KV form keeps the ring position in a register instead: unrolled, hipcc runs it out of registers and its spill
+  // reloads -- each behind an s_waitcnt vmcnt(0) -- would drain the prefetch.)
+  constexpr int UNR = SPLIT ? 1 : (DMA ? 3 : 2);
+  int st3 = 0;
+  for (int j0 = jt0; j0 < jt1; j0 += UNR) {
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) {
+    const int j = j0 + u;
+    if (j >= jt1) break;
+    const int cur = UNR == 1 ? st3 : u;
     const char* sK = smem + cur * STAGE;
     const char* sV = sK + VOFF;
     // every wave is past the barrier that ended tile j-1, so the stage that held it is free: tile j+2 goes there and has
     // two tile-times to land
-    const int st_free = st3 == 0 ? 2 : st3 - 1;
+    const int st_free = UNR == 1 ? (st3 == 0 ? 2 : st3 - 1) : (u + 2) % 3;
+    // (opaque to the optimiser on purpose: otherwise it keeps the eight lane offsets zero-extended to 64 bits -- sixteen
+    // registers -- live across the whole loop and spills; re-extending them costs the DMA waves eight VALU per tile)
+    asm volatile("" : "+v"(d_k0), "+v"(d_k1), "+v"(d_k2), "+v"(d_k3), "+v"(d_v0), "+v"(d_v1), "+v"(d_v2), "+v"(d_v3));
     if (DMA && j + 2 < jt1) AT_DMA(j + 2, st_free);
     STAMP(0)
 
@@ -296,16 +320,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
         kf[s][1] = *reinterpret_cast<const v4i*>(sK + at_off8(32 + fr, 2 * s + fh));
       }
       typedef float f32x4 __attribute__((ext_vector_type(4)));
-      f32x4 sk0[4], sb0[4], sk1[4], sb1[4];  // key scales / constants of the two 32-key blocks, 4 consecutive keys each
-      {
-        const uint32_t sa = lds_base + cur * STAGE + AT_SC8 + 16 * fh;
+      f32x4 sk0[4], sb0[4];  // key scales / constants of one 32-key block, 4 consecutive keys each
+      const uint32_t sa = lds_base + cur * STAGE + AT_SC8 + 16 * fh;
 #define AT_SC(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(sa), "n"(off))
-        AT_SC(sk0[0], 0); AT_SC(sk0[1], 32); AT_SC(sk0[2], 64); AT_SC(sk0[3], 96);
-        AT_SC(sk1[0], 128); AT_SC(sk1[1], 160); AT_SC(sk1[2], 192); AT_SC(sk1[3], 224);
-        AT_SC(sb0[0], 256); AT_SC(sb0[1], 288); AT_SC(sb0[2], 320); AT_SC(sb0[3], 352);
-        AT_SC(sb1[0], 384); AT_SC(sb1[1], 416); AT_SC(sb1[2], 448); AT_SC(sb1[3], 480);
-#undef AT_SC
-      }
+      AT_SC(sk0[0], 0); AT_SC(sk0[1], 32); AT_SC(sk0[2], 64); AT_SC(sk0[3], 96);
+      AT_SC(sb0[0], 256); AT_SC(sb0[1], 288); AT_SC(sb0[2], 320); AT_SC(sb0[3], 352);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         if (s + 2 < 4) {
@@ -316,20 +335,24 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
         a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[s][0], qf8[s], a0, 0, 0, 0);
         a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[s][1], qf8[s], a1, 0, 0, 0);
       }
-      // t = dot * delta_k: register 4g+e holds key 8g + 4fh + e (+32 for the second block).  The 16 scale / constant reads
-      // are inline asm for the reason the V reads are (hipcc would put s_waitcnt vmcnt(0) in front of a plain LDS load
-      // while an LDS-DMA is in flight and drain the prefetch); they were issued ahead of the MFMAs above.
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(sk0[0]), "+v"(sk0[1]), "+v"(sk0[2]), "+v"(sk0[3]), "+v"(sb0[0]), "+v"(sb0[1]), "+v"(sb0[2]), "+v"(sb0[3]),
-                     "+v"(sk1[0]), "+v"(sk1[1]), "+v"(sk1[2]), "+v"(sk1[3]), "+v"(sb1[0]), "+v"(sb1[1]), "+v"(sb1[2]), "+v"(sb1[3]));
+      // t = dot * delta_k: register 4g+e holds key 8g + 4fh + e (+32 for the second block).  The scale / constant reads are
+      // inline asm for the reason the V reads are (hipcc would put s_waitcnt vmcnt(0) in front of a plain LDS load while an
+      // LDS-DMA is in flight and drain the prefetch); the first block's were issued ahead of the MFMAs above.
+#define AT_SCWAIT() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sk0[0]), "+v"(sk0[1]), "+v"(sk0[2]), "+v"(sk0[3]), "+v"(sb0[0]), "+v"(sb0[1]), "+v"(sb0[2]), "+v"(sb0[3]))
+      AT_SCWAIT();
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          s0[4 * g + e] = fmaf(__int_as_float(a0[4 * g + e]), sk0[g][e], sb0[g][e]);
-          s1[4 * g + e] = fmaf(__int_as_float(a1[4 * g + e]), sk1[g][e], sb1[g][e]);
-        }
-      }
+        for (int e = 0; e < 4; ++e) s0[4 * g + e] = fmaf(__int_as_float(a0[4 * g + e]), sk0[g][e], sb0[g][e]);
+      AT_SC(sk0[0], 128); AT_SC(sk0[1], 160); AT_SC(sk0[2], 192); AT_SC(sk0[3], 224);
+      AT_SC(sb0[0], 384); AT_SC(sb0[1], 416); AT_SC(sb0[2], 448); AT_SC(sb0[3], 480);
+      AT_SCWAIT();
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s1[4 * g + e] = fmaf(__int_as_float(a1[4 * g + e]), sk0[g][e], sb0[g][e]);
+#undef AT_SC
+#undef AT_SCWAIT
     } else if (DMA) {
       // K fragments run three d-slices ahead of the MFMAs that consume them
       bf16x8 kf[8][2];
@@ -345,16 +368,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
           kf[s + 3][1] = *reinterpret_cast<const bf16x8*>(sK + at_off(32 + fr, 2 * (s + 3) + fh));
         }
         __builtin_amdgcn_sched_barrier(0);
-        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s][0], qf[s], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s][1], qf[s], s1, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s][0], qf[s], s == 0 ? sinit : s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s][1], qf[s], s == 0 ? sinit : s1, 0, 0, 0);
       }
     } else {
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(sK + at_off(fr, 2 * s + fh));
         const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(sK + at_off(32 + fr, 2 * s + fh));
-        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s], s1, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s], s == 0 ? sinit : s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s], s == 0 ? sinit : s1, 0, 0, 0);
       }
     }
     STAMP(1)
@@ -376,27 +399,60 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    // Running max, rescaled lazily: the accumulators are touched only when some query's max grew by more than 2^6
-    // (exp2 domain) since the last rescale (wave-uniform vote), so P stays <= 64 instead of <= 1 -- same 8
-    // significant bits in bf16, fp32 accumulators unaffected -- and the 64-multiply rescale of O^T almost never runs
-    // after the first tiles (+3.4 % measured).
-    if (__any((mx - m_run) * c > 6.0f)) {
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-    }
-    const float mc = m_run * c;
     float ls = 0.f;
+    if (QK8) {
+      // scores are dot * delta_k here; c = delta_q * scale * log2(e) is per lane.  Running max, rescaled lazily: the
+      // accumulators are touched only when some query's max grew by more than 2^6 (exp2 domain) since the last rescale
+      // (wave-uniform vote), so P stays <= 64 instead of <= 1 -- same 8 significant bits in bf16, fp32 accumulators unaffected.
+      if (__any((mx - m_run) * c > 6.0f)) {
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        m_run = m_new;
+        l_run *= alpha;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc));
-      s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc));
-      ls += s0[r] + s1[r];
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      }
+      const float mc = m_run * c;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc));
+        s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc));
+        ls += s0[r] + s1[r];
+      }
+    } else {
+      // The accumulators hold s * scale * log2(e) - m_run already (Q carries the scale, the MFMA chains started from -m_run),
+      // so mx is the growth of the row maximum over the reference and p = exp2(acc) with no further arithmetic.  The first
+      // tile fixes the reference at its own maximum (whatever its sign); later the reference only grows, lazily: when some
+      // query's maximum exceeds it by more than 2^6 (wave-uniform vote) -- P stays <= 64 instead of <= 1, the same 8
+      // significant bits in bf16 -- and then O, l and this tile's scores are brought to the new reference.
+      const bool first = (j == jt0);
+      if (first || __any(mx > 6.0f)) {
+        asm volatile("" ::: "memory");  // keep this a branch
+        const float delta = first ? mx : fmaxf(mx, 0.f);
+        if (!first) {
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+          l_run *= alpha;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        }
+        m_run = first ? delta : m_run + delta;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s0[r] -= delta;
+          s1[r] -= delta;
+          sinit[r] = -m_run;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = __builtin_amdgcn_exp2f(s0[r]);
+        s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+        ls += s0[r] + s1[r];
+      }
     }
     l_run += ls;
     bf16x8 pf[4];  // key slice ks = 2*block + t: registers 8t..8t+7 of that block's accumulator
@@ -477,6 +533,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
     }
     STAMP(5)
   }
+  }
 #ifdef WANQ_ATTN_STAMP
   if (blockIdx.x == 7 && blockIdx.y == 3 && lane == 0) {
     for (int i = 0; i < 6; ++i) g_stamp[wave * 16 + i] = acc_[i];
@@ -496,7 +553,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
           *reinterpret_cast<float4*>(po + 32 * db + 8 * g) = make_float4(o[db][4 * g], o[db][4 * g + 1], o[db][4 * g + 2], o[db][4 * g + 3]);
       if (fh == 0) {
         float* pm = p.part_ml + (((int64_t)blockIdx.z * p.Lq + qr) * p.H + head) * 2;
-        pm[0] = QK8 ? m_run * (c / p.c) : m_run;  // the merge kernel applies the global scale p.c: fold this query's delta_q in
+        // the merge kernel computes exp2((m - M) * p.c): hand it m in raw-score units (QK8: fold this query's delta_q in;
+        // bf16 form: m_run already carries scale * log2(e))
+        pm[0] = QK8 ? m_run * (c / p.c) : m_run / p.c;
         pm[1] = l_tot;
       }
     }
