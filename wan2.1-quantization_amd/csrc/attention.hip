@@ -414,13 +414,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
       }
-      const float mc = m_run * c;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc));
-        s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc));
-        ls += s0[r] + s1[r];
-      }
     } else {
       // The accumulators hold s * scale * log2(e) - m_run already (Q carries the scale, the MFMA chains started from -m_run),
       // so mx is the growth of the row maximum over the reference and p = exp2(acc) with no further arithmetic.  The first
@@ -447,22 +440,23 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
           sinit[r] = -m_run;
         }
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s0[r] = __builtin_amdgcn_exp2f(s0[r]);
-        s1[r] = __builtin_amdgcn_exp2f(s1[r]);
-        ls += s0[r] + s1[r];
-      }
     }
-    l_run += ls;
-    bf16x8 pf[4];  // key slice ks = 2*block + t: registers 8t..8t+7 of that block's accumulator
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      pf[0][e] = (__bf16)s0[e];
-      pf[1][e] = (__bf16)s0[8 + e];
-      pf[2][e] = (__bf16)s1[e];
-      pf[3][e] = (__bf16)s1[8 + e];
-    }
+    // P of key slice ks = 2*block + t (registers 8t..8t+7 of that block's accumulator), two scores at a time so that the
+    // pieces can be placed between the P.V MFMAs of the previous slice (below): p = exp2(acc) (QK8: exp2(t * c - m * c))
+    const float mc = QK8 ? m_run * c : 0.f;
+    bf16x8 pf[4];
+#define AT_EXP2(ks, e)                                                                                      \
+  {                                                                                                         \
+    float x0_ = ((ks) < 2 ? s0 : s1)[8 * ((ks) & 1) + (e)], x1_ = ((ks) < 2 ? s0 : s1)[8 * ((ks) & 1) + (e) + 1]; \
+    x0_ = __builtin_amdgcn_exp2f(QK8 ? fmaf(x0_, c, -mc) : x0_);                                            \
+    x1_ = __builtin_amdgcn_exp2f(QK8 ? fmaf(x1_, c, -mc) : x1_);                                            \
+    ls += x0_ + x1_;                                                                                        \
+    asm volatile("" : "+v"(ls)); /* keep the row-sum adds here, in the MFMA's shadow (hipcc sinks the chain to the tile's end) */ \
+    pf[ks][e] = (__bf16)x0_;                                                                                \
+    pf[ks][(e) + 1] = (__bf16)x1_;                                                                          \
+  }
+#define AT_EXP8(ks) AT_EXP2(ks, 0) AT_EXP2(ks, 2) AT_EXP2(ks, 4) AT_EXP2(ks, 6)
+    if (!DMA) { AT_EXP8(0) AT_EXP8(1) AT_EXP8(2) AT_EXP8(3) }
 
     STAMP(2)
     // ---------------- next tile: registers -> other LDS stage, then fetch the tile after it
@@ -490,18 +484,37 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
   o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_join(P##2, P##3), pf[ks], o[1], 0, 0, 0);              \
   o[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_join(P##4, P##5), pf[ks], o[2], 0, 0, 0);              \
   o[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_join(P##6, P##7), pf[ks], o[3], 0, 0, 0)
+      // The exponentials of slice ks+1 are placed, two at a time, behind each of the four MFMAs of slice ks: an MFMA holds the
+      // SIMD's issue port for 8 of its 32 cycles, so 2 x v_exp (8 cycles each) + their add / convert fit in its shadow and the
+      // wave's own softmax overlaps its own matrix work (before: all 32 exponentials, then all 16 MFMAs).
+#define AT_PV1(P, a, b, ks, db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_join(P##a, P##b), pf[ks], o[db], 0, 0, 0)
+#define AT_FENCE() __builtin_amdgcn_sched_barrier(0)
       AT_TR8(ta, 0);
       AT_TR8(tb, 1);
+      AT_EXP8(0)
+      AT_FENCE();
       AT_WAIT8(ta, 8);
-      AT_PV4(ta, 0);
+      AT_PV1(ta, 0, 1, 0, 0); AT_FENCE(); AT_EXP2(1, 0) AT_FENCE();
+      AT_PV1(ta, 2, 3, 0, 1); AT_FENCE(); AT_EXP2(1, 2) AT_FENCE();
+      AT_PV1(ta, 4, 5, 0, 2); AT_FENCE(); AT_EXP2(1, 4) AT_FENCE();
+      AT_PV1(ta, 6, 7, 0, 3); AT_FENCE(); AT_EXP2(1, 6) AT_FENCE();
       AT_TR8(ta, 2);
       AT_WAIT8(tb, 8);
-      AT_PV4(tb, 1);
+      AT_PV1(tb, 0, 1, 1, 0); AT_FENCE(); AT_EXP2(2, 0) AT_FENCE();
+      AT_PV1(tb, 2, 3, 1, 1); AT_FENCE(); AT_EXP2(2, 2) AT_FENCE();
+      AT_PV1(tb, 4, 5, 1, 2); AT_FENCE(); AT_EXP2(2, 4) AT_FENCE();
+      AT_PV1(tb, 6, 7, 1, 3); AT_FENCE(); AT_EXP2(2, 6) AT_FENCE();
       AT_TR8(tb, 3);
       AT_WAIT8(ta, 8);
-      AT_PV4(ta, 2);
+      AT_PV1(ta, 0, 1, 2, 0); AT_FENCE(); AT_EXP2(3, 0) AT_FENCE();
+      AT_PV1(ta, 2, 3, 2, 1); AT_FENCE(); AT_EXP2(3, 2) AT_FENCE();
+      AT_PV1(ta, 4, 5, 2, 2); AT_FENCE(); AT_EXP2(3, 4) AT_FENCE();
+      AT_PV1(ta, 6, 7, 2, 3); AT_FENCE(); AT_EXP2(3, 6) AT_FENCE();
       AT_WAIT8(tb, 0);
       AT_PV4(tb, 3);
+      l_run += ls;
+#undef AT_PV1
+#undef AT_FENCE
 #undef AT_TR
 #undef AT_TR8
 #undef AT_WAIT8
@@ -519,7 +532,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
           o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_join(lo, hi), pf[ks], o[db], 0, 0, 0);
         }
       }
+      l_run += ls;
     }
+#undef AT_EXP8
+#undef AT_EXP2
     STAMP(3)
     if (DMA) {
       // tile j+1 must have landed; the eight instructions of tile j+2 (if issued; waves 4-7 issue none) may stay in flight
