@@ -286,6 +286,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
   // VALU instructions per tile out of the loop.
   // (The split-KV form keeps the ring position in a register instead: unrolled, hipcc runs it out of registers and its spill
   // reloads -- each behind an s_waitcnt vmcnt(0) -- would drain the prefetch.)
+  // Static priority for the second-dispatched half of the workgroup: waves 4-7 lose every VALU / MFMA arbitration against
+  // their SIMD partners (priority, then age) and are the critical path of a tile (phase stamps: S 1219 vs 786 cycles, P.V
+  // 1500 vs 1100); one s_setprio for the whole kernel, no per-phase flips (+0.6 % measured, A/B in one process).
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
   constexpr int UNR = SPLIT ? 1 : (DMA ? 3 : 2);
   int st3 = 0;
   for (int j0 = jt0; j0 < jt1; j0 += UNR) {
