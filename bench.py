@@ -167,6 +167,9 @@ def main():
     ap.add_argument("--no-quality", action="store_true")
     ap.add_argument("--quant-config", dest="quant_config", default="w8a8_all_linears.yaml", help="file under quant_configs/")
     ap.add_argument("--no-cfg-parallel", action="store_true", help="pure Ulysses over all GPUs (needs heads %% N == 0)")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("WANQ_BENCH_GRAPH", "1")), choices=[0, 1],
+                    help="1 (default, single GPU only): the two DiT passes of a step are replayed from a captured HIP graph "
+                         "(wan/graph.py); 0: every kernel is launched eagerly")
     ap.add_argument("--preset", default=os.environ.get("WANQ_BENCH_PRESET", ""), choices=["", "14B-ulysses"],
                     help="14B-ulysses = the second north-star target: --model t2v-14B --size 1280*720 --no-cfg-parallel "
                          "(Ulysses degree = N; also selectable with WANQ_BENCH_PRESET in the environment)")
@@ -241,16 +244,25 @@ def main():
         del fp
         torch.cuda.empty_cache()
 
+    from wan.utils.fused_step import FusedStep
+    fused = FusedStep(sched, args.guide, latent0)  # CFG combine + UniPC update: one kernel per step
+    graphed = None
+    use_graph = [bool(args.graph) and world == 1]
+    if use_graph[0]:
+        from wan.graph import GraphedPasses
+        graphed = GraphedPasses(model, latent0, [ctx_c, ctx_u], seq_len)
+
     def step(latent, i):
         t = sched.timesteps[i:i + 1]
-        if plan.cfg_degree == 2:  # my half of the GPUs runs ONE of the two passes; a 2 MB all-gather joins them
+        if graphed is not None and use_graph[0]:
+            cond, uncond = graphed(latent, t)
+        elif plan.cfg_degree == 2:  # my half of the GPUs runs ONE of the two passes; a 2 MB all-gather joins them
             mine = model([latent], t, [ctx_c if plan.cfg_index == 0 else ctx_u], seq_len, plan.sp)[0]
             cond, uncond = plan.gather_cfg(mine)
         else:
             cond = model([latent], t, [ctx_c], seq_len, plan.sp)[0]
             uncond = model([latent], t, [ctx_u], seq_len, plan.sp)[0]
-        noise = uncond + args.guide * (cond - uncond)
-        return sched.step(noise, sched.timesteps[i], latent)
+        return fused.step(cond, uncond, latent, sched.timesteps[i])
 
     latent = latent0
     for i in range(args.warmup):
@@ -275,6 +287,7 @@ def main():
     # ---- per-kernel timing for the roofline objects: the same K steps once more, with a HIP event pair around every GEMM /
     # attention launch on the launch stream (about 1400 pairs per step, which is why they stay out of the headline region
     # above; `instrumented_ms_per_step` shows what they cost).  share_of_step = kernel time / wall time of THIS region.
+    use_graph[0] = False  # launches must be eager to be bracketed by events
     timer = GemmTimer()
     atimer = GemmTimer()
     qgemm.set_timer(timer)
@@ -298,6 +311,8 @@ def main():
                                f"ViDiT-Q scale+rotate alpha=0.5665 on {n_vidit} self-attn q/k/v layers), "
                                f"{args.size}x{args.frames}f, latent {list(shape)}, L={seq_len}, cond+uncond+CFG+scheduler per step",
                    "quant_config": args.quant_config, "attention": "bf16", "parallelism": plan.describe(),
+                   "launch": "hip graph replay of the two DiT passes + 1 fused CFG/scheduler kernel" if graphed is not None else
+                             "eager launches + 1 fused CFG/scheduler kernel",
                    "rccl_ranks": dist.get_world_size() if world > 1 else 1},
     }
     # Two MFMA-bound kernels carry the step: the bf16 flash attention (the dominant one at L = 32760) and the int8 GEMM

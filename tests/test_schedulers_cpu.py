@@ -60,3 +60,79 @@ def test_unipc_order2_beats_euler_on_a_curved_field():
     e_err = abs(run(FlowMatchScheduler(1000), 20) - exact)
     u_err = abs(run(FlowUniPCMultistepScheduler(1000), 20) - exact)
     assert u_err < 0.2 * e_err
+
+
+def test_dpmpp_first_step_constant_field_and_convergence():
+    """FlowDPMSolverMultistepScheduler (--sample_solver dpm++): the schedule of get_sampling_sigmas (reference
+    fm_solvers.py:22-26: starts at sigma = 1, where alpha = 0), the first step is the flow-matching Euler step, a constant
+    velocity field is integrated exactly, and the 2M update converges faster than Euler on a curved field."""
+    from wan.utils.fm_solvers import FlowDPMSolverMultistepScheduler, FlowMatchScheduler, get_sampling_sigmas
+
+    n = 10
+    s = FlowDPMSolverMultistepScheduler(1000)
+    s.set_timesteps(n, shift=5.0)
+    sig = get_sampling_sigmas(n, 5.0)
+    assert sig[0] == 1.0 and len(s.sigmas) == n + 1 and s.sigmas[-1] == 0.0
+    np.testing.assert_allclose(s.sigmas[:-1], sig.astype(np.float32), rtol=0, atol=0)
+    assert int(s.timesteps[0]) == 1000
+    x = torch.randn(4, 5, generator=torch.Generator().manual_seed(0))
+    v = torch.randn(4, 5, generator=torch.Generator().manual_seed(1))
+    y = s.step(v, s.timesteps[0], x)
+    torch.testing.assert_close(y, x + (s.sigmas[1] - s.sigmas[0]) * v, rtol=1e-6, atol=1e-6)
+    # constant velocity: x(sigma) = x1 + (sigma - 1) v exactly, for every step
+    s.set_timesteps(n, shift=5.0)
+    z = x.clone()
+    for t in s.timesteps:
+        z = s.step(v, t, z)
+    torch.testing.assert_close(z, x - v, rtol=1e-5, atol=1e-5)
+
+    # curved field: x' = dx/dsigma = a * x  ->  x(0) = x(1) * exp(-a); velocity model v(x) = a x
+    def run(make, steps):
+        sc = make()
+        sc.set_timesteps(steps, shift=1.0)
+        z = torch.ones(1, dtype=torch.float64)
+        for t in sc.timesteps:
+            vv = 0.7 * z
+            z = sc.step(vv, t, z) if "timestep" in sc.step.__code__.co_varnames else sc.step(vv, z)
+        return abs(float(z) - np.exp(-0.7))
+
+    e2 = [run(lambda: FlowDPMSolverMultistepScheduler(1000), k) for k in (20, 40)]
+    e1 = [run(lambda: FlowMatchScheduler(1000), k) for k in (20, 40)]
+    # (the reference keeps its sigmas in fp32, which puts a ~4e-5 floor under the second-order error here)
+    assert e2[0] < e1[0] * 0.05 and e2[1] < e1[1] * 0.05 and max(e2) < 1e-4, (e1, e2)
+
+
+def test_fused_step_equals_scheduler_for_all_solvers():
+    """FusedStep (CFG combine + scheduler update as ONE linear combination per step, coefficients derived by running the
+    scheduler's own step() on symbolic linear forms) reproduces the plain `noise = u + g (c - u); x = sched.step(...)` loop for
+    UniPC, DPM++ and Euler.  The GPU kernel is replaced by its definition here (out[o] = sum_i coef[o][i] in[i])."""
+    import wan.utils.fused_step as fs
+    from wan.utils.fm_solvers import FlowDPMSolverMultistepScheduler, FlowMatchScheduler
+    from wan.utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
+
+    def definition(coef_dev, ins, outs):
+        c = coef_dev.view(-1)[:len(outs) * len(ins)].view(len(outs), len(ins))
+        for o in range(len(outs)):
+            outs[o].copy_(sum(c[o, i] * ins[i] for i in range(len(ins))))
+
+    saved = fs.lincomb
+    fs.lincomb = definition
+    try:
+        for mk in (lambda: FlowUniPCMultistepScheduler(1000, shift=1.0), lambda: FlowDPMSolverMultistepScheduler(1000),
+                   lambda: FlowMatchScheduler(1000)):
+            a, b = mk(), mk()
+            a.set_timesteps(9, device="cpu", shift=5.0)
+            b.set_timesteps(9, device="cpu", shift=5.0)
+            g = torch.Generator().manual_seed(0)
+            x = torch.randn(16, 3, 8, 8, generator=g)
+            xa, xb = x.clone(), x.clone()
+            f = fs.FusedStep(b, 5.0, like=x)
+            for t in a.timesteps:
+                c, u = torch.randn(x.shape, generator=g), torch.randn(x.shape, generator=g)
+                noise = u + 5.0 * (c - u)
+                xa = a.step(noise, t, xa) if fs._takes_timestep(a) else a.step(noise, xa)
+                xb = f.step(c, u, xb, t)
+                assert float((xa - xb).abs().max() / xa.abs().max()) < 1e-5
+            assert f.n_launch == 9
+    finally:
+        fs.lincomb = saved

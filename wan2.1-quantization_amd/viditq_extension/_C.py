@@ -32,6 +32,7 @@ PROTOTYPES = {
     "wanq_gate_residual": [_vp, _i, _vp, _i, _i64, _vp, _i, _vp, _i, _i64, _i, _i64, _vp],
     "wanq_gemm_w8a8": [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i64, _i, _i, _vp],
     "wanq_gemm_w4a8": [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i64, _i, _i, _vp],
+    "wanq_lincomb": [_i, _i, _vp, _vp, _vp, _i64, _vp],
     "wanq_col_absmax": [_vp, _i, _vp, _i64, _i, _vp],
     "wanq_row_minmax": [_vp, _i, _vp, _vp, _vp, _i64, _i, _vp],
     "wanq_weight_quant": [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _i64, _i, _vp],

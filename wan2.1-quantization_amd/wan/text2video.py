@@ -15,7 +15,8 @@ import torch
 
 from .configs import latent_shape, seq_len_for
 from .modules.model import WanModel
-from .utils.fm_solvers import FlowMatchScheduler
+from .utils.fm_solvers import FlowDPMSolverMultistepScheduler, FlowMatchScheduler
+from .utils.fused_step import FusedStep
 from .utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
 
 logger = logging.getLogger(__name__)
@@ -86,11 +87,13 @@ class WanT2V:
             raise NotImplementedError(f"Unsupported solver {sample_solver}")
         if sample_solver == "unipc":    # the reference's default (text2video.py:215-222)
             sched = FlowUniPCMultistepScheduler(self.num_train_timesteps, shift=1.0)
-        elif sample_solver == "euler":  # first-order flow-matching update
+        elif sample_solver == "dpm++":  # text2video.py:223-232: sigmas from get_sampling_sigmas(steps, shift)
+            sched = FlowDPMSolverMultistepScheduler(self.num_train_timesteps, shift=1.0)
+        else:                           # first-order flow-matching update
             sched = FlowMatchScheduler(self.num_train_timesteps, shift=1.0)
-        else:
-            raise NotImplementedError("dpm++ is not implemented; use unipc (default) or euler")
         sched.set_timesteps(sampling_steps, device=self.device, shift=shift)
+        # guidance + scheduler update as one kernel per step (wan/utils/fused_step.py) on the GPU
+        fused = FusedStep(sched, guide_scale, latent) if latent.is_cuda else None
         plan = self.plan
         sp = plan.sp if plan is not None else None
         kw = {"sp": sp} if sp is not None and sp.size > 1 else {}
@@ -103,8 +106,11 @@ class WanT2V:
                 else:
                     cond = self.model([latent], ts, [context], seq_len, **kw)[0]
                     uncond = self.model([latent], ts, [context_null], seq_len, **kw)[0]
-                noise_pred = uncond + guide_scale * (cond - uncond)
-                latent = sched.step(noise_pred, t, latent) if sample_solver == "unipc" else sched.step(noise_pred, latent)
+                if fused is not None:
+                    latent = fused.step(cond.float(), uncond.float(), latent, t)
+                else:
+                    noise_pred = uncond + guide_scale * (cond - uncond)
+                    latent = sched.step(noise_pred, latent) if sample_solver == "euler" else sched.step(noise_pred, t, latent)
                 if step_callback is not None:
                     step_callback(i, latent)
         return latent
