@@ -167,9 +167,9 @@ def main():
     ap.add_argument("--no-quality", action="store_true")
     ap.add_argument("--quant-config", dest="quant_config", default="w8a8_all_linears.yaml", help="file under quant_configs/")
     ap.add_argument("--no-cfg-parallel", action="store_true", help="pure Ulysses over all GPUs (needs heads %% N == 0)")
-    ap.add_argument("--graph", type=int, default=int(os.environ.get("WANQ_BENCH_GRAPH", "1")), choices=[0, 1],
-                    help="1 (default, single GPU only): the two DiT passes of a step are replayed from a captured HIP graph "
-                         "(wan/graph.py); 0: every kernel is launched eagerly")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("WANQ_BENCH_GRAPH", "0")), choices=[0, 1],
+                    help="1 (single GPU only): the two DiT passes of a step are replayed from a captured HIP graph "
+                         "(wan/graph.py); 0 (default): every kernel is launched eagerly -- measured the same (DESIGN.md 5): the host runs ahead")
     ap.add_argument("--preset", default=os.environ.get("WANQ_BENCH_PRESET", ""), choices=["", "14B-ulysses"],
                     help="14B-ulysses = the second north-star target: --model t2v-14B --size 1280*720 --no-cfg-parallel "
                          "(Ulysses degree = N; also selectable with WANQ_BENCH_PRESET in the environment)")

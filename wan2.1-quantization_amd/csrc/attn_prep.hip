@@ -50,16 +50,21 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const PrepParams p) {
   float v[NCH][8];
   bool ok[NCH];
   float ss = 0.f;
+  // one dtype branch per row (a branch per chunk serialises the row's loads: see rowwise.hip load_row)
+#define PREP_LOAD_ROW(T)                                                       \
+  _Pragma("unroll") for (int i = 0; i < NCH; ++i) {                            \
+    const int c0 = (sub * 64 + lane + i * 64 * WPR) * 8;                       \
+    ok[i] = c0 < C;                                                            \
+    if (ok[i]) Io<T>::load8(p.x, rbase + c0, v[i]);                            \
+  }
+  if (p.x_dtype == WANQ_F32) { PREP_LOAD_ROW(F32) } else if (p.x_dtype == WANQ_BF16) { PREP_LOAD_ROW(BF16) } else { PREP_LOAD_ROW(F16) }
+#undef PREP_LOAD_ROW
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c0 = (sub * 64 + lane + i * 64 * WPR) * 8;
-    ok[i] = c0 < C;
+  for (int i = 0; i < NCH; ++i)
     if (ok[i]) {
-      prep_load8(p.x, p.x_dtype, rbase + c0, v[i]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
     }
-  }
   ss = wave_sum(ss);
   if (WPR > 1) {
     if (lane == 0) slots[wave] = ss;

@@ -49,6 +49,54 @@ __device__ __forceinline__ void store8_rt(void* base, int dt, int64_t elem, cons
   else Io<F32>::store8(base, elem, v);
 }
 
+// One dtype branch per ROW, not per chunk: with a branch per chunk hipcc waits for each load (s_waitcnt vmcnt(0) at the
+// branch's end) before it issues the next one, and a row's NCH loads run back to back in latency instead of in parallel.
+template <typename T, int WPR, int NCH>
+__device__ __forceinline__ void load_row_t(const void* x, int64_t rbase, int sub, int lane, int C, float (&v)[NCH][8], bool (&ok)[NCH]) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c0 = (sub * 64 + lane + i * 64 * WPR) * 8;
+    ok[i] = c0 < C;
+    if (ok[i]) {
+      Io<T>::load8(x, rbase + c0, v[i]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    }
+  }
+}
+template <int WPR, int NCH>
+__device__ __forceinline__ void load_row(const void* x, int dt, int64_t rbase, int sub, int lane, int C, float (&v)[NCH][8], bool (&ok)[NCH]) {
+  if (dt == WANQ_F32) load_row_t<F32, WPR, NCH>(x, rbase, sub, lane, C, v, ok);
+  else if (dt == WANQ_BF16) load_row_t<BF16, WPR, NCH>(x, rbase, sub, lane, C, v, ok);
+  else load_row_t<F16, WPR, NCH>(x, rbase, sub, lane, C, v, ok);
+}
+// v <- v * m (MUL) / v * (1 + m) (MUL1P) / v + m (ADD) with a per-column vector m, same dispatch
+enum { MOD_MUL = 0, MOD_MUL1P = 1, MOD_ADD = 2 };
+template <typename T, int OP, int WPR, int NCH>
+__device__ __forceinline__ void mod_row_t(const void* m, int64_t mbase, int sub, int lane, float (&v)[NCH][8], const bool (&ok)[NCH]) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+    if (ok[i]) {
+      float t[8];
+      Io<T>::load8(m, mbase + (sub * 64 + lane + i * 64 * WPR) * 8, t);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = OP == MOD_MUL ? v[i][j] * t[j] : OP == MOD_MUL1P ? v[i][j] * (1.0f + t[j]) : v[i][j] + t[j];
+    }
+}
+template <int OP, int WPR, int NCH>
+__device__ __forceinline__ void mod_row(const void* m, int dt, int64_t mbase, int sub, int lane, float (&v)[NCH][8], const bool (&ok)[NCH]) {
+  if (dt == WANQ_F32) mod_row_t<F32, OP, WPR, NCH>(m, mbase, sub, lane, v, ok);
+  else if (dt == WANQ_BF16) mod_row_t<BF16, OP, WPR, NCH>(m, mbase, sub, lane, v, ok);
+  else mod_row_t<F16, OP, WPR, NCH>(m, mbase, sub, lane, v, ok);
+}
+template <typename T, int WPR, int NCH>
+__device__ __forceinline__ void store_row_t(void* out, int64_t rbase, int sub, int lane, const float (&v)[NCH][8], const bool (&ok)[NCH]) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+    if (ok[i]) Io<T>::store8(out, rbase + (sub * 64 + lane + i * 64 * WPR) * 8, v[i]);
+}
+
 template <int WPR>
 struct RowReduce {
   // LDS slots: one float per wave per reduction id; every reduction id is used once per kernel, so a
@@ -101,17 +149,7 @@ __global__ __launch_bounds__(256) void rowwise_kernel(const RowParams p) {
 
   float v[NCH][8];
   bool ok[NCH];
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c0 = (sub * 64 + lane + i * 64 * WPR) * 8;
-    ok[i] = c0 < C;
-    if (ok[i]) {
-      load8_rt(p.x, p.x_dtype, rbase + c0, v[i]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
-    }
-  }
+  load_row<WPR, NCH>(p.x, p.x_dtype, rbase, sub, lane, C, v, ok);
 
   if (LN) {
     float s = 0.f;
@@ -135,26 +173,16 @@ __global__ __launch_bounds__(256) void rowwise_kernel(const RowParams p) {
     const int64_t mb = (row / p.rows_per_batch) * p.mod_stride;
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
-      if (ok[i]) {
-        const int c0 = (sub * 64 + lane + i * 64 * WPR) * 8;
-        float g[8], sh[8], sc[8];
-        if (p.gamma) load8_rt(p.gamma, p.mod_dtype, c0, g);
-        if (p.mscale) load8_rt(p.mscale, p.mod_dtype, mb + c0, sc);
-        if (p.mshift) load8_rt(p.mshift, p.mod_dtype, mb + c0, sh);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float y = (v[i][j] - mean) * rstd;
-          if (p.gamma) y *= g[j];
-          if (p.mscale) y *= (1.0f + sc[j]);
-          if (p.mshift) y += sh[j];
-          v[i][j] = y;
-        }
-      }
+      for (int j = 0; j < 8; ++j) v[i][j] = (v[i][j] - mean) * rstd;
+    if (p.gamma) mod_row<MOD_MUL, WPR, NCH>(p.gamma, p.mod_dtype, 0, sub, lane, v, ok);
+    if (p.mscale) mod_row<MOD_MUL1P, WPR, NCH>(p.mscale, p.mod_dtype, mb, sub, lane, v, ok);
+    if (p.mshift) mod_row<MOD_ADD, WPR, NCH>(p.mshift, p.mod_dtype, mb, sub, lane, v, ok);
   } else if (p.act == 1) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[i][j] = gelu_tanh_f32(v[i][j]);
+      for (int j = 0; j < 8; ++j) v[i][j] = gelu_tanh_fast_f32(v[i][j]);  // branch-free form (3e-6 rel): libm tanhf x 8 NCH bloats every variant
   }
 
   if (p.premul) {
@@ -168,9 +196,9 @@ __global__ __launch_bounds__(256) void rowwise_kernel(const RowParams p) {
       }
   }
   if (p.out_fp) {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i)
-      if (ok[i]) store8_rt(p.out_fp, p.out_dtype, rbase + (sub * 64 + lane + i * 64 * WPR) * 8, v[i]);
+    if (p.out_dtype == WANQ_F32) store_row_t<F32, WPR, NCH>(p.out_fp, rbase, sub, lane, v, ok);
+    else if (p.out_dtype == WANQ_BF16) store_row_t<BF16, WPR, NCH>(p.out_fp, rbase, sub, lane, v, ok);
+    else store_row_t<F16, WPR, NCH>(p.out_fp, rbase, sub, lane, v, ok);
   }
   if (!p.q) return;
 
