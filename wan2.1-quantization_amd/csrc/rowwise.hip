@@ -173,8 +173,10 @@ __global__ __launch_bounds__(256) void rowwise_kernel(const RowParams p) {
     const int64_t mb = (row / p.rows_per_batch) * p.mod_stride;
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
+      if (ok[i]) {  // chunks past the row end stay zero: they take part in the row max and sum
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[i][j] = (v[i][j] - mean) * rstd;
+        for (int j = 0; j < 8; ++j) v[i][j] = (v[i][j] - mean) * rstd;
+      }
     if (p.gamma) mod_row<MOD_MUL, WPR, NCH>(p.gamma, p.mod_dtype, 0, sub, lane, v, ok);
     if (p.mscale) mod_row<MOD_MUL1P, WPR, NCH>(p.mscale, p.mod_dtype, mb, sub, lane, v, ok);
     if (p.mshift) mod_row<MOD_ADD, WPR, NCH>(p.mshift, p.mod_dtype, mb, sub, lane, v, ok);
