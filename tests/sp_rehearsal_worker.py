@@ -76,10 +76,24 @@ def main():
     sl = seq_len_for(shape, sp_size=world)
     out = model([latent], t, [ctx_c], sl, plan.sp)[0]
     e_sp = rel(out, ref_c)
+
+    def fsdp_leg():
+        """--dit_fsdp on top of Ulysses: every block's integer weights live 1/P per rank and are gathered one block ahead."""
+        before = sum(b.ffn0.weight.numel() for b in model.hip_blocks)
+        sh = model.shard_blocks(None)
+        assert sh.P == world and sum(b.ffn0.weight.numel() for b in model.hip_blocks) == 0 and before > 0
+        e = 0.0
+        for _ in range(2):  # second pass picks up the wrapped-around prefetch of block 0
+            e = max(e, rel(model([latent], t, [ctx_c], sl, plan.sp)[0], ref_c))
+        torch.cuda.synchronize()
+        print(f"RANK {rank} fsdp_rel={e:.3e} shard_bytes={sh.shard_bytes} blocks={len(sh.blocks)}", flush=True)
+        assert e == 0.0, e
+
     if os.environ.get("WANQ_REHEARSE_NO_CFG_PARALLEL") == "1":  # config 4 runs pure Ulysses (bench.py --no-cfg-parallel)
         torch.cuda.synchronize()
         print(f"RANK {rank} sp_rel={e_sp:.3e} cfg_rel=skipped finite={bool(torch.isfinite(out).all())}", flush=True)
         assert e_sp == 0.0, e_sp
+        fsdp_leg()
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -96,6 +110,7 @@ def main():
     # attention kernel 1 head per launch instead of 4, same arithmetic per head -- so it is bit-equal too.
     assert e_cfg == 0.0, e_cfg
     assert e_sp == 0.0, e_sp
+    fsdp_leg()
     dist.barrier()
     dist.destroy_process_group()
 

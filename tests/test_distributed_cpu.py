@@ -160,3 +160,76 @@ def test_head_chunks_and_split_kv_policy():
     assert ops.attention_splits(32760, 32760, 2, cpu, ncu=256) == 1  # exactly one full round
     assert ops.attention_splits(32760, 32760, 1, cpu, ncu=256) >= 2
     assert ops.attention_splits(32760, 512, 12, cpu, ncu=256) == 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# --dit_fsdp: block weights sharded over the ranks, all-gathered one block ahead (wan/distributed/fsdp.py)
+class _ToyLin:
+    def __init__(self, w):
+        self.weight = w
+
+
+class _ToyAttn:
+    def __init__(self, g, dim, dtype):
+        for l in "qkvo":
+            setattr(self, l, _ToyLin(_toy_w(g, dim, dim, dtype)))
+
+
+def _toy_w(g, n, k, dtype):
+    import torch
+    if dtype == torch.uint8:
+        return torch.randint(0, 256, (n, k // 2), generator=g, dtype=torch.uint8)
+    return torch.randint(-128, 128, (n, k), generator=g, dtype=torch.int8)
+
+
+class _ToyBlock:
+    """The attribute layout of WanAttentionBlockWithHipKernel that ShardedBlocks walks (self_attn / cross_attn q,k,v,o; ffn0/2)."""
+
+    def __init__(self, seed, dim=48, ffn=80):
+        import torch
+        g = torch.Generator().manual_seed(seed)
+        self.self_attn, self.cross_attn = _ToyAttn(g, dim, torch.int8), _ToyAttn(g, dim, torch.int8)
+        self.ffn0, self.ffn2 = _ToyLin(_toy_w(g, ffn, dim, torch.uint8)), _ToyLin(_toy_w(g, dim, ffn, torch.uint8))  # packed W4
+
+    def checksum(self):
+        import torch
+        tot = torch.zeros((), dtype=torch.int64)
+        for a in (self.self_attn, self.cross_attn):
+            for l in "qkvo":
+                tot += getattr(a, l).weight.to(torch.int64).sum() * 3 + getattr(a, l).weight[0, 1].to(torch.int64)
+        return int(tot + self.ffn0.weight.to(torch.int64).sum() * 5 + self.ffn2.weight.to(torch.int64)[1, 2])
+
+
+def _fsdp_worker(rank, world, port, q):
+    import traceback
+    try:
+        import torch
+        _init(rank, world, port)
+        from wan.distributed.fsdp import ShardedBlocks
+
+        blocks = [_ToyBlock(s) for s in range(int(os.environ.get('WANQ_TOY_BLOCKS', '5')))]
+        want = [b.checksum() for b in blocks]
+        full = sum(getattr(a, l).weight.numel() for a in (blocks[0].self_attn, blocks[0].cross_attn) for l in "qkvo") + \
+            blocks[0].ffn0.weight.numel() + blocks[0].ffn2.weight.numel()
+        sh = ShardedBlocks(blocks, None)
+        assert sh.P == world and sh.full_bytes >= full and sh.full_bytes % (16 * world) == 0
+        assert all(s.numel() == sh.full_bytes // world for s in sh.shards)
+        assert blocks[2].ffn0.weight.numel() == 0  # the block gave up its storage
+        assert sh.bytes_per_rank() < len(blocks) * full / world + 2 * sh.full_bytes + 1
+        got = []
+        for _ in range(2):  # two passes (cond / uncond) reuse the double buffer
+            got = []
+            sh.run(lambda b: got.append(b.checksum()))
+            assert got == want, (rank, got, want)
+            assert blocks[-1].self_attn.q.weight.numel() == 0  # released after use
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("n_blocks", [5, 4])  # even counts also prefetch the next pass's block 0 behind the last block
+def test_dit_fsdp_shard_gather_roundtrip_world2(n_blocks, monkeypatch):
+    monkeypatch.setenv("WANQ_TOY_BLOCKS", str(n_blocks))
+    _run(_fsdp_worker, 2, 29671 + n_blocks)

@@ -24,6 +24,7 @@ def test_two_ranks_on_one_gpu_match_single_rank():
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, f"rehearsal failed:\n{r.stdout[-4000:]}\n{r.stderr[-4000:]}"
     assert r.stdout.count("sp_rel=") == 2, r.stdout[-2000:]
+    assert r.stdout.count("fsdp_rel=0.000e+00") == 2, r.stdout[-2000:]  # --dit_fsdp: sharded block weights, bit-equal
 
 
 def test_two_ranks_ulysses_at_14b_block_dims():
@@ -35,6 +36,7 @@ def test_two_ranks_ulysses_at_14b_block_dims():
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, f"14B-dims rehearsal failed:\n{r.stdout[-4000:]}\n{r.stderr[-4000:]}"
     assert r.stdout.count("sp_rel=0.000e+00") == 2, r.stdout[-2000:]
+    assert r.stdout.count("fsdp_rel=0.000e+00") == 2, r.stdout[-2000:]
 
 
 def test_bench_multi_rank_control_flow_rehearsal():

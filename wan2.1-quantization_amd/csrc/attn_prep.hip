@@ -38,7 +38,8 @@ __device__ __forceinline__ void prep_store8(void* base, int dt, int64_t elem, co
   else Io<F32>::store8(base, elem, v);
 }
 
-template <int WPR, int NCH>
+// Q8: also emit the per-(token, head) int8 form (a template flag so that the plain kernel keeps its register count)
+template <int WPR, int NCH, bool Q8>
 __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const PrepParams p) {
   __shared__ float slots[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const PrepParams p) {
       }
     }
     if (p.out) prep_store8(p.out, p.out_dtype, rbase + c0, v[i]);
-    if (p.q8) {  // head_dim == 128: a head is the 16 chunks of 16 consecutive lanes
+    if (Q8) {  // head_dim == 128: a head is the 16 chunks of 16 consecutive lanes
       float m = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[i][j]));
@@ -140,8 +141,11 @@ static int rmsnorm_rope_impl(const void* x, int x_dtype, const float* weight, co
                q8, qscale, scale_stride};
   hipStream_t st = (hipStream_t)stream;
   const int chunks = cols / 8;
-#define WANQ_PR(WPR, NCH) \
-  hipLaunchKernelGGL((rmsnorm_rope_kernel<WPR, NCH>), dim3((unsigned)((WPR) == 1 ? (rows + 3) / 4 : rows)), dim3(256), 0, st, p)
+#define WANQ_PR(WPR, NCH)                                                                                                  \
+  do {                                                                                                                     \
+    if (q8) hipLaunchKernelGGL((rmsnorm_rope_kernel<WPR, NCH, true>), dim3((unsigned)((WPR) == 1 ? (rows + 3) / 4 : rows)), dim3(256), 0, st, p); \
+    else hipLaunchKernelGGL((rmsnorm_rope_kernel<WPR, NCH, false>), dim3((unsigned)((WPR) == 1 ? (rows + 3) / 4 : rows)), dim3(256), 0, st, p);   \
+  } while (0)
   if (chunks <= 64) WANQ_PR(1, 1);
   else if (chunks <= 128) WANQ_PR(1, 2);
   else if (chunks <= 192) WANQ_PR(1, 3);

@@ -36,7 +36,14 @@ def main(args):
         model.bitwidth_refactor()
     model.set_init_done()
     if args.hardware:
-        model.hardware_forward_refactor()
+        iw = os.path.join(args.output_dir, "checkpoint", "int_weight.pt")
+        # the reference exports the integer checkpoint and loads it into the kernel-mode blocks (quant_generate.py:397-409);
+        # ptq_wanx.py already wrote it next to quant_params.pth: load it when it is there
+        model.hardware_forward_refactor(iw if os.path.exists(iw) else None)
+        if args.dit_fsdp and world > 1:  # FULL_SHARD of the DiT blocks (wan/distributed/fsdp.py): integer weights over all ranks
+            sh = model.shard_blocks(None)
+            logging.info("dit_fsdp: %.1f MB of block weights per rank (of %.1f MB)", sh.bytes_per_rank() / 1e6,
+                         len(sh.blocks) * sh.full_bytes / 1e6)
     else:
         assert plan.sp_degree == 1, "sequence parallelism needs kernel mode"
     t2v = WanT2V(cfg, device_id=local, rank=rank, model=model.eval(), plan=plan, context_file=args.context_file)

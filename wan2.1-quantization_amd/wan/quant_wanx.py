@@ -26,6 +26,7 @@ class QuantWanModel(WanModel, QuantModel):
         self.q_cfg = quant_config
         self.quant_param_dict = {}
         self.hip_blocks = None
+        self._fsdp = None
         self._rope_cache = {}
 
     @classmethod
@@ -154,6 +155,15 @@ class QuantWanModel(WanModel, QuantModel):
             logger.info("loaded %d tensors of the integer checkpoint %s into the kernel-mode blocks", taken, load_path)
         return self
 
+    def shard_blocks(self, group=None):
+        """`--dit_fsdp` (reference wan/distributed/fsdp.py:10-32, text2video.py:106-107): shard the kernel-mode blocks' integer
+        weights over the ranks of `group`; forward() then all-gathers one block ahead of the one it is computing."""
+        from .distributed.fsdp import ShardedBlocks
+
+        assert self.hip_blocks is not None, "shard_blocks applies to kernel mode (call hardware_forward_refactor first)"
+        self._fsdp = ShardedBlocks(self.hip_blocks, group)
+        return self._fsdp
+
     def software_forward(self):
         self.hip_blocks = None
         return self
@@ -180,8 +190,12 @@ class QuantWanModel(WanModel, QuantModel):
                     rope = rope[sp.rank * lp:(sp.rank + 1) * lp]
                 h = h.contiguous()
                 cq = _FpSrc(ctx[0].float().contiguous(), self.hip_blocks[0].act_dtype)
-                for blk in self.hip_blocks:
-                    blk(h, e0.float(), rope, seq_lens[0], cq, sp)
+                if getattr(self, "_fsdp", None) is not None:
+                    e0f, L0 = e0.float(), seq_lens[0]
+                    self._fsdp.run(lambda blk: blk(h, e0f, rope, L0, cq, sp))
+                else:
+                    for blk in self.hip_blocks:
+                        blk(h, e0.float(), rope, seq_lens[0], cq, sp)
                 out = self.head(h.unsqueeze(0), e)
                 if sp is not None and sp.size > 1:
                     out = sp.all_gather_rows(out[0]).unsqueeze(0)

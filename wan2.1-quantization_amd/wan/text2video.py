@@ -46,8 +46,12 @@ class WanT2V:
         self.sp_size = plan.sp_degree if plan is not None else 1
         self.plan = plan
         self.context_file = context_file
-        if dit_fsdp or t5_fsdp:
-            logger.info("--dit_fsdp / --t5_fsdp accepted: weights are replicated (int8 14B = 14 GB << 288 GB HBM)")
+        if dit_fsdp and hasattr(model, "shard_blocks") and getattr(model, "hip_blocks", None) is not None \
+                and getattr(model, "_fsdp", None) is None and plan is not None and plan.world > 1:
+            model.shard_blocks(None)  # kernel-mode blocks: integer weights 1/P per rank (wan/distributed/fsdp.py)
+        elif dit_fsdp or t5_fsdp:
+            logger.info("--dit_fsdp / --t5_fsdp: sharding applies to the kernel-mode DiT blocks (QuantWanModel.shard_blocks); "
+                        "the FP model and the text encoder stay replicated (bf16 14B = 28 GB << 288 GB HBM)")
         if model is not None:
             self.model = model
         elif checkpoint_dir and os.path.exists(os.path.join(checkpoint_dir, "config.json")):
