@@ -22,7 +22,7 @@ def cfg(**extra):
     return qcfg.create(dict({"weight": {"n_bits": 8, "sym": False}, "act": {"n_bits": 8, "sym": True}}, **extra))
 
 
-@pytest.mark.parametrize("n", [1536, 5120])
+@pytest.mark.parametrize("n", [1536, 5120, 8960])
 def test_rotation_kernel_vs_reference_hadamard_products(golden, n):
     """out_fp of wanq_rotate_quant_rows == hadU(x) of the reference (golden a5), fp32 vs fp64: 1e-5."""
     import viditq_extension.fused as fused
@@ -41,7 +41,7 @@ def test_rotation_kernel_vs_reference_hadamard_products(golden, n):
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=2e-5)
 
 
-@pytest.mark.parametrize("n,rows", [(1536, 131), (5120, 37), (4096, 16), (128, 9)])
+@pytest.mark.parametrize("n,rows", [(1536, 131), (5120, 37), (4096, 16), (128, 9), (8960, 1), (8960, 1031)])
 def test_rotate_quant_codes_vs_oracle(n, rows):
     import viditq_extension.fused as fused
     from qdiff.quarot import quarot_utils as qu
@@ -161,6 +161,83 @@ def test_viditq_linear_vs_reference_golden(golden):
     # rotation_matrix property materialises the reference's matrix
     R = vl.rotation_matrix
     np.testing.assert_allclose(R.cpu().numpy()[[0, 1, 777, n - 1]], qr.hadamard_from_signs(g["signs"])[[0, 1, 777, n - 1]], atol=1e-15)
+
+
+def test_rotate_8960_dtypes_and_outputs():
+    """n = 8960 = 140 x 64 (csrc/rotate140.hip: Paley-140 mix on the matrix cores with a three-way bf16 split of the fp32
+    values): bf16 / fp16 input as the GELU output has it, fp output in every dtype, scale / sum vectors in fp16 too."""
+    import viditq_extension.fused as fused
+    from qdiff.quarot import quarot_utils as qu
+
+    n, rows = 8960, 67
+    g = torch.Generator().manual_seed(8960)
+    x = (torch.randn(rows, n, generator=g) * torch.exp(0.7 * torch.randn(n, generator=g))).clamp_min(-0.17)  # GELU-like
+    x[5] = 0  # an all-zero token: the eps rule
+    pm = (torch.rand(n, generator=g) + 0.5) * (torch.randint(0, 2, (n,), generator=g) * 2 - 1)
+    rot = qu.kernel_rotation_params(n, DEV)
+    assert rot[0] == 140
+    for dt in (torch.bfloat16, torch.float16, torch.float32):
+        xd = x.to(dt)
+        ref = qr.matmul_hadU(xd.double().numpy() * pm.double().numpy())
+        oq, oscale = qr.dynamic_quantize_sym(ref.astype(np.float32))
+        scale, ssum = torch.zeros(rows, device=DEV), torch.zeros(rows, device=DEV)
+        out = torch.empty(rows, n, device=DEV)
+        q = fused.rotate_quant(xd.to(DEV), pm.to(DEV), rot, ssum, scale, out_fp=out)
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=3e-6 * np.abs(ref).max())
+        np.testing.assert_allclose(scale.cpu().numpy(), oscale, rtol=2e-6)
+        d = np.abs(q.cpu().numpy().astype(np.int32) - oq)
+        assert d.max() <= 1 and (d != 0).mean() < 2e-3
+        np.testing.assert_allclose(ssum.cpu().numpy(), q.cpu().numpy().astype(np.int64).sum(1) * scale.cpu().numpy().astype(np.float64),
+                                   rtol=1e-6, atol=1e-6)
+        assert scale[5].item() == pytest.approx(1e-6) and int(q[5].abs().max()) == 0
+    # 16-bit fp output and fp16 vectors
+    for odt in (torch.bfloat16, torch.float16):
+        out = torch.empty(rows, n, dtype=odt, device=DEV)
+        s16, m16 = torch.zeros(rows, dtype=torch.float16, device=DEV), torch.zeros(rows, dtype=torch.float16, device=DEV)
+        fused.rotate_quant(x.to(DEV), pm.to(DEV), rot, m16, s16, out_fp=out)
+        ref = qr.matmul_hadU(x.double().numpy() * pm.double().numpy())
+        np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=2 ** -8, atol=1e-6)
+        np.testing.assert_allclose(s16.float().cpu().numpy(), np.maximum(np.abs(ref).max(1) / 127, 1e-6), rtol=2e-3, atol=1e-7)
+    # the LayerNorm forms have no 8960 variant (no model dimension is 8960): refused, not mis-computed
+    with pytest.raises(RuntimeError, match="8960"):
+        fused.layernorm_rotate_quant(torch.empty(4, n, dtype=torch.int8, device=DEV), x[:4].to(DEV), None, None, None, pm.to(DEV), rot,
+                                     torch.zeros(4, device=DEV), torch.zeros(4, device=DEV), 1e-6)
+
+
+def test_viditq_linear_8960_vs_oracle():
+    """The 1.3B ffn.2 shape (in_features 8960) as a ViDiT layer: mask, double-quantised rotated weight and forward vs the
+    oracle (x @ R evaluated as hadU(x * signs): quarot_utils.py:186-192)."""
+    from qdiff.viditq.viditq_quant_layer import ViDiTQuantizedLinear
+
+    n, out, rows = 8960, 48, 33
+    g = torch.Generator().manual_seed(140)
+    w = torch.randn(out, n, generator=g) * 0.02 * torch.exp(0.5 * torch.randn(n, generator=g))
+    b = torch.randn(out, generator=g) * 0.1
+    x = torch.randn(rows, n, generator=g) * torch.exp(0.8 * torch.randn(n, generator=g))
+    act_mask = x.abs().amax(0).clamp_min(1e-3)
+    signs = (torch.randint(0, 2, (n,), generator=g) * 2 - 1).double()
+    lin = torch.nn.Linear(n, out).to(DEV)
+    lin.weight.data, lin.bias.data = w.to(DEV), b.to(DEV)
+    vl = ViDiTQuantizedLinear(n, out, True, DEV, cfg(viditq={"alpha": 0.5665, "layer_name_regex": ""}), lin)
+    vl.get_channel_mask(act_mask.to(DEV))
+    mask = qr.vidit_channel_mask(w.numpy(), act_mask.numpy(), 0.5665)
+    np.testing.assert_allclose(vl.channel_mask.cpu().numpy(), mask, rtol=3e-7)
+    vl.channel_mask = torch.from_numpy(mask).to(DEV)
+    vl.rotation_signs = signs
+    vl.update_quantized_weight_rotated_and_scaled()
+    w1, _, _ = qr.static_fake_quant((w.numpy() / mask[None, :]).astype(np.float32), 8, False)
+    w2in = qr.matmul_hadU(w1.astype(np.float64) * signs.numpy()[None, :]).astype(np.float32)
+    # the kernel's transform is fp32: the rotated weight is within an ulp or two of the fp64 product, so delta / zp agree to
+    # rounding and a code moves only at a .5 boundary
+    w2, d2, z2 = qr.static_fake_quant(w2in, 8, False)
+    np.testing.assert_allclose(vl.w_quantizer.delta.reshape(-1).cpu().numpy(), d2.reshape(-1), rtol=2e-6)
+    dw = np.abs(vl.weight.data.cpu().numpy() - w2) / d2.reshape(-1, 1)
+    assert dw.max() <= 1.0 + 1e-3 and (dw > 0.5).mean() < 2e-3
+    xt = qr.matmul_hadU((x.numpy() * mask[None, :]).astype(np.float32).astype(np.float64) * signs.numpy()[None, :]).astype(np.float32)
+    xq, xs = qr.dynamic_quantize_sym(xt)
+    y_ref = (xq.astype(np.float64) * xs[:, None]) @ w2.astype(np.float64).T + b.numpy()
+    y = vl(x.to(DEV))
+    assert np.abs(y.cpu().numpy() - y_ref).max() < 5e-3 * np.abs(y_ref).max() + 1e-3
 
 
 def test_surgery_save_load_roundtrip_and_mixed_precision():

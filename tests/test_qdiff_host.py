@@ -72,7 +72,9 @@ def test_torch_hadamard_matches_reference_products(golden, n):
 def test_hadamard_size_rules():
     with pytest.raises(AssertionError):
         qu.get_hadK(13824)  # the reference asserts too
-    assert qu.kernel_rotation_params(8960, "cpu") is None  # 140 x 64: block < 128, no fused kernel
+    k, h = qu.kernel_rotation_params(8960, "cpu")  # 140 x 64: its own kernel (csrc/rotate140.hip), Paley matrix of order 140
+    assert k == 140 and h.shape == (140, 140) and torch.equal(h @ h.T, 140 * torch.eye(140))
+    assert qu.kernel_rotation_params(140 * 32, "cpu") is None  # any other block < 128: no fused kernel
     k, h = qu.kernel_rotation_params(1536, "cpu")
     assert k == 12 and h.shape == (12, 12) and torch.equal(h @ h.T, 12 * torch.eye(12))
     k, h = qu.kernel_rotation_params(4096, "cpu")

@@ -50,6 +50,12 @@ report("quant bf16 -> int8 [L,1536] (attention output)", timeit(lambda: fused.qu
 report("rotate+quant bf16 -> int8 [L,1536]", timeit(lambda: fused.rotate_quant(xb, pms[0], rot, u_, s_)), L * C * 3)
 hb = torch.randn(L, F, device=DEV, generator=g).to(torch.bfloat16)
 report("quant bf16 -> int8 [L,8960] (GELU output)", timeit(lambda: fused.quant_sum(hb, u_, s_)), L * F * 3)
+rot_f = qu.kernel_rotation_params(F, DEV)
+pm_f = torch.randn(F, device=DEV, generator=g)
+qf = None
+t_f = timeit(lambda: fused.rotate_quant(hb, pm_f, rot_f, u_, s_))
+report("rotate(140x64, MFMA mix)+quant bf16 -> int8 [L,8960]", t_f, L * F * 3)
+print(f"{'':58s} {2 * 140 * 140 * 64 * 3 * L / t_f / 1e12:8.1f} TFLOP/s bf16 MFMA (3-term split, unpadded)")
 w = torch.ones(C, device=DEV)
 rope = torch.randn(L, 64, 2, device=DEV, generator=g)
 qb = torch.randn(L, C, device=DEV, generator=g).to(torch.bfloat16)

@@ -463,7 +463,7 @@ static int check_rotation(const char* what, int had_k, int cols) {
                "%s: the transform is (H_K (x) H_128): cols=%d must be had_k * 128 (had_k=%d)", what, cols, had_k);
   const bool pow2 = (had_k & (had_k - 1)) == 0;
   WANQ_REQUIRE((pow2 && had_k <= 32) || had_k == 12 || had_k == 40, WANQ_E_SHAPE,
-               "%s: cols=%d has no fused Hadamard transform (supported: 2^p in [128, 4096], 1536, 5120)", what, cols);
+               "%s: cols=%d has no fused Hadamard transform here (supported: 2^p in [128, 4096], 1536, 5120; 8960 without LayerNorm)", what, cols);
   return WANQ_OK;
 }
 
@@ -486,6 +486,10 @@ extern "C" int wanq_rotate_quant_rows(const void* x, int x_dtype, const float* p
     return premul_quant_rows(false, x, x_dtype, nullptr, nullptr, nullptr, 0, 1, 0.f, premul, out_fp, out_dtype, q, scale, sum,
                              vec_dtype, rows, cols, (hipStream_t)stream, what);
   if (int e = check_rows(what, rows)) return e;
+  if (had_k == 140) {  // 8960 = 140 x 64: the Paley-140 mix runs on the matrix cores (rotate140.hip)
+    WANQ_REQUIRE(cols == 8960, WANQ_E_SHAPE, "%s: had_k=140 is the transform of cols=8960 (got %d)", what, cols);
+    return rotate140_rows(x, x_dtype, premul, out_fp, out_dtype, q, scale, sum, vec_dtype, rows, (hipStream_t)stream, what);
+  }
   if (int e = check_rotation(what, had_k, cols)) return e;
   if (rows == 0) return WANQ_OK;
   RotParams p{};

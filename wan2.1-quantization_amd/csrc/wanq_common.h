@@ -36,6 +36,10 @@ int premul_quant_rows(bool ln, const void* x, int x_dtype, const void* gamma, co
                       int64_t mod_stride, int64_t rows_per_batch, float eps, const float* premul, void* out_fp, int out_dtype,
                       int8_t* q, void* scale, void* sum, int vec_dtype, int64_t rows, int cols, hipStream_t st, const char* what);
 
+// rotate140.hip: the n = 8960 = 140 x 64 transform (+ per-token quantiser)
+int rotate140_rows(const void* x, int x_dtype, const float* premul, void* out_fp, int out_dtype, int8_t* q, void* scale, void* sum,
+                   int vec_dtype, int64_t rows, hipStream_t st, const char* what);
+
 inline bool is_fp(int dt) { return dt == WANQ_F16 || dt == WANQ_BF16 || dt == WANQ_F32; }
 inline bool is_vec(int dt) { return dt == WANQ_F16 || dt == WANQ_F32; }
 

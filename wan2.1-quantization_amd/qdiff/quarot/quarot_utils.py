@@ -84,10 +84,13 @@ def random_hadamard_matrix(size, device, signs=None):
 def kernel_rotation_params(n, device):
     """(had_k, hadk fp32 [K',K'] or None) for wanq_rotate_quant_rows, i.e. hadU written as (H_K' (x) H_128)/sqrt(n)
     with K' = K * m/128.  Only had_k crosses the C boundary (the library generates the same table from n); hadk is returned
-    for host-side checks.  None when the library has no kernel for n: block size m < 128 (8960 = 140 x 64) or a K' outside
+    for host-side checks.  n = 8960 = 140 x 64 has its own kernel (csrc/rotate140.hip: had_k = 140, 64-wide blocks, no
+    LayerNorm form).  None when the library has no kernel for n: any other block size m < 128 or a K' outside
     {2^p <= 32, 12, 40} (csrc/rotate.hip)."""
     hadK, K = get_hadK(n)
     m = n // K
+    if n == 8960:
+        return 140, hadK.float().contiguous().to(device)
     if m < 128:
         return None
     kk = K * (m // 128)
