@@ -146,6 +146,15 @@ int wanq_rmsnorm_rope_q8(const void* x, int x_dtype, const float* weight, const 
                          int out_dtype, int8_t* q8, float* qscale, int64_t scale_stride, int64_t rows, int cols,
                          int head_dim, int64_t rows_per_batch, int64_t positions, float eps, void* stream);
 
+/* The same as wanq_rmsnorm_rope with the store scattered per head: head h (head_dim columns) of row r lands at
+ * out + head_map[2h] + r * head_map[2h+1] (elements of out_dtype).  head_map: DEVICE int64 [cols/head_dim][2].
+ * Writes the Ulysses head-scatter all-to-all send buffers ([P][rows][w] per head chunk) directly, in place of the
+ * permute + contiguous pack the reference's all_to_all_4D does around the collective
+ * (ViDiT-Q/examples/Wan2.1/wan/distributed/xdit_context_parallel.py:147-192, yunchang SeqAllToAll4D). */
+int wanq_rmsnorm_rope_scatter(const void* x, int x_dtype, const float* weight, const float* rope, void* out,
+                              int out_dtype, const int64_t* head_map, int64_t rows, int cols, int head_dim,
+                              int64_t rows_per_batch, int64_t positions, float eps, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Flash-attention forward, non-causal:  o[q,h,:] = softmax_k(q[q,h,:].k[k,h,:] * scale) v[k,h,:] over the
  * first Lk keys.  Token-major tensors [tokens, heads*head_dim] with a token stride in ELEMENTS (so q/k/v may

@@ -233,3 +233,45 @@ def _fsdp_worker(rank, world, port, q):
 def test_dit_fsdp_shard_gather_roundtrip_world2(n_blocks, monkeypatch):
     monkeypatch.setenv("WANQ_TOY_BLOCKS", str(n_blocks))
     _run(_fsdp_worker, 2, 29671 + n_blocks)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Ulysses send images written in place by the producer (SeqParallel.packed_layout / scatter_packed)
+def _packed_worker(rank, world, port, q):
+    import traceback
+    try:
+        import torch
+        _init(rank, world, port)
+        from wan.distributed.parallel import SeqParallel
+
+        sp = SeqParallel(None)
+        lp, heads, d = 5, 8, 4  # 8 heads over `world` ranks, head chunks of 1 + 2 + 1 heads (world 2)
+        c = heads * d
+        g = c // world
+        hp = heads // world
+        chunks = [(0, d), (d, (hp - 1) * d), ((hp - 1) * d, g)] if hp >= 3 else [(0, g)]
+        x = (torch.arange(lp * c, dtype=torch.float32).view(lp, c) + 1000 * rank)
+        numel, hmap, where = sp.packed_layout(lp, c, d, chunks, "cpu")
+        assert numel == lp * c and hmap.shape == (heads, 2) and len(where) == len(chunks)
+        # what wanq_rmsnorm_rope_scatter's store does, in index form
+        flat = torch.full((numel,), float("nan"))
+        for h in range(heads):
+            for r in range(lp):
+                o = int(hmap[h, 0]) + r * int(hmap[h, 1])
+                flat[o:o + d] = x[r, h * d:(h + 1) * d]
+        assert not torch.isnan(flat).any()  # the images tile the buffer exactly
+        for (c0, c1), (off, w) in zip(chunks, where):
+            a = sp.scatter_packed(flat, lp, off, w)
+            b = sp.scatter_heads(x, cols=(c0, c1))
+            assert torch.equal(a, b), (rank, c0, c1)
+            pa = sp.scatter_packed(flat, lp, off, w, async_op=True).wait()
+            assert torch.equal(pa, b)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        q.put((rank, traceback.format_exc()))
+
+
+def test_packed_send_images_equal_transpose_pack_world2():
+    _run(_packed_worker, 2, 29691)

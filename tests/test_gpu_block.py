@@ -46,6 +46,31 @@ def test_rmsnorm_rope_vs_oracle(dtype):
                                rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize("dim,heads,P,chunks_h", [(1536, 12, 4, [(0, 1), (1, 3)]), (1536, 12, 2, [(0, 2), (2, 4), (4, 6)]),
+                                                  (5120, 40, 8, [(0, 5)]), (512, 4, 2, [(0, 1), (1, 2)])])
+def test_rmsnorm_rope_scatter_writes_the_ulysses_send_images(dim, heads, P, chunks_h):
+    """wanq_rmsnorm_rope_scatter == wanq_rmsnorm_rope followed by the [Lp, P, w] -> [P, Lp, w] pack of every head chunk,
+    bit for bit (the store address changes, nothing else)."""
+    from wan import ops
+    from wan.distributed.parallel import SeqParallel
+
+    d, lp = 128, 77
+    g = torch.Generator().manual_seed(dim + P)
+    x = torch.randn(lp, dim, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.rand(dim, generator=g) + 0.5).to(DEV)
+    table = ops.rope_table(wr.rope_freqs(d), (7, 11, 1), DEV)
+    sp = SeqParallel(False)
+    sp.size = P  # layout arithmetic only
+    chunks = [(a * d, b * d) for a, b in chunks_h]
+    numel, hmap, where = sp.packed_layout(lp, dim, d, chunks, DEV)
+    flat = ops.rmsnorm_rope_scatter(x, w, table, d, torch.full((numel,), float("nan"), dtype=torch.bfloat16, device=DEV), hmap, eps=1e-6)
+    ref = ops.rmsnorm_rope_(x.clone(), w, table, d, eps=1e-6)
+    assert not torch.isnan(flat.float()).any()
+    for (c0, c1), (off, wd) in zip(chunks, where):
+        want = ref.view(lp, P, dim // P)[:, :, c0:c1].transpose(0, 1).contiguous()
+        assert torch.equal(flat[off:off + P * lp * wd].view(P, lp, wd), want)
+
+
 def make_block(dim, ffn, heads, seed):
     from wan.modules.model import WanAttentionBlock
 

@@ -25,6 +25,9 @@ struct PrepParams {
   int8_t* q8;
   float* qscale;
   int64_t scale_stride;
+  // optional scattered store (SC): head h of row r goes to out + head_map[2h] + r * head_map[2h+1] (elements) instead of the
+  // row-major [rows, cols] image -- the kernel writes the Ulysses all-to-all send buffers ([P][rows][w] per head chunk) directly
+  const int64_t* head_map;
 };
 
 __device__ __forceinline__ void prep_load8(const void* base, int dt, int64_t elem, float (&v)[8]) {
@@ -39,7 +42,7 @@ __device__ __forceinline__ void prep_store8(void* base, int dt, int64_t elem, co
 }
 
 // Q8: also emit the per-(token, head) int8 form (a template flag so that the plain kernel keeps its register count)
-template <int WPR, int NCH, bool Q8>
+template <int WPR, int NCH, bool Q8, bool SC = false>
 __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const PrepParams p) {
   __shared__ float slots[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -97,7 +100,12 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const PrepParams p) {
         v[i][2 * k + 1] = a * cs[2 * k + 1] + b * cs[2 * k];
       }
     }
-    if (p.out) prep_store8(p.out, p.out_dtype, rbase + c0, v[i]);
+    if (SC) {
+      const int hd = c0 / p.head_dim;
+      prep_store8(p.out, p.out_dtype, p.head_map[2 * hd] + row * p.head_map[2 * hd + 1] + (c0 - hd * p.head_dim), v[i]);
+    } else if (p.out) {
+      prep_store8(p.out, p.out_dtype, rbase + c0, v[i]);
+    }
     if (Q8) {  // head_dim == 128: a head is the 16 chunks of 16 consecutive lanes
       float m = 0.f;
 #pragma unroll
@@ -126,7 +134,7 @@ using namespace wanq;
 
 static int rmsnorm_rope_impl(const void* x, int x_dtype, const float* weight, const float* rope, void* out, int out_dtype,
                              int8_t* q8, float* qscale, int64_t scale_stride, int64_t rows, int cols, int head_dim,
-                             int64_t rows_per_batch, int64_t positions, float eps, void* stream) {
+                             int64_t rows_per_batch, int64_t positions, float eps, void* stream, const int64_t* head_map = nullptr) {
   WANQ_REQUIRE(x && (out || q8), WANQ_E_ARG, "wanq_rmsnorm_rope: NULL pointer");
   WANQ_REQUIRE(!q8 || (qscale && head_dim == 128 && cols % 128 == 0 && scale_stride >= rows), WANQ_E_ARG,
                "wanq_rmsnorm_rope_q8: needs qscale, head_dim == 128, cols %% 128 == 0 and scale_stride >= rows");
@@ -138,12 +146,13 @@ static int rmsnorm_rope_impl(const void* x, int x_dtype, const float* weight, co
   WANQ_REQUIRE(rows >= 0 && rows < (1ll << 31) && rows_per_batch >= 1, WANQ_E_SHAPE, "wanq_rmsnorm_rope: bad rows");
   if (rows == 0) return WANQ_OK;
   PrepParams p{x, out, weight, rope, x_dtype, out_dtype, rows, rows_per_batch, positions, cols, head_dim > 0 ? head_dim : 8, eps,
-               q8, qscale, scale_stride};
+               q8, qscale, scale_stride, head_map};
   hipStream_t st = (hipStream_t)stream;
   const int chunks = cols / 8;
 #define WANQ_PR(WPR, NCH)                                                                                                  \
   do {                                                                                                                     \
     if (q8) hipLaunchKernelGGL((rmsnorm_rope_kernel<WPR, NCH, true>), dim3((unsigned)((WPR) == 1 ? (rows + 3) / 4 : rows)), dim3(256), 0, st, p); \
+    else if (head_map) hipLaunchKernelGGL((rmsnorm_rope_kernel<WPR, NCH, false, true>), dim3((unsigned)((WPR) == 1 ? (rows + 3) / 4 : rows)), dim3(256), 0, st, p); \
     else hipLaunchKernelGGL((rmsnorm_rope_kernel<WPR, NCH, false>), dim3((unsigned)((WPR) == 1 ? (rows + 3) / 4 : rows)), dim3(256), 0, st, p);   \
   } while (0)
   if (chunks <= 64) WANQ_PR(1, 1);
@@ -173,4 +182,19 @@ extern "C" int wanq_rmsnorm_rope_q8(const void* x, int x_dtype, const float* wei
   WANQ_REQUIRE(q8, WANQ_E_ARG, "wanq_rmsnorm_rope_q8: q8 is required");
   return rmsnorm_rope_impl(x, x_dtype, weight, rope, out, out_dtype, q8, qscale, scale_stride, rows, cols, head_dim,
                            rows_per_batch, positions, eps, stream);
+}
+
+// RMSNorm + RoPE with the store scattered per head: head h (head_dim columns) of row r lands at
+// out + head_map[2h] + r * head_map[2h+1] (elements of out_dtype; head_map is a DEVICE array of 2 * cols/head_dim int64).
+// Writes the Ulysses head-scatter send buffers in place of the torch transpose().contiguous() pack (the reference's
+// all_to_all_4D, ViDiT-Q/examples/Wan2.1/wan/distributed/xdit_context_parallel.py:147-192 via yunchang, does the same permute
+// + contiguous on the host side of the collective).
+extern "C" int wanq_rmsnorm_rope_scatter(const void* x, int x_dtype, const float* weight, const float* rope, void* out,
+                                         int out_dtype, const int64_t* head_map, int64_t rows, int cols, int head_dim,
+                                         int64_t rows_per_batch, int64_t positions, float eps, void* stream) {
+  WANQ_REQUIRE(out && head_map, WANQ_E_ARG, "wanq_rmsnorm_rope_scatter: NULL pointer");
+  WANQ_REQUIRE(head_dim >= 8 && head_dim % 8 == 0 && cols % head_dim == 0, WANQ_E_SHAPE,
+               "wanq_rmsnorm_rope_scatter: head_dim=%d must be a multiple of 8 dividing cols=%d", head_dim, cols);
+  return rmsnorm_rope_impl(x, x_dtype, weight, rope, out, out_dtype, nullptr, nullptr, 0, rows, cols, head_dim, rows_per_batch,
+                           positions, eps, stream, head_map);
 }

@@ -86,6 +86,36 @@ class SeqParallel:
         post = lambda r: r.view(P * lp, w)  # noqa: E731  blocks arrive in rank order == sequence order
         return _Pending(work, recv, post) if async_op else post(recv)
 
+    # ---- send images written by the producer kernel (no pack pass) ---------------------------------------------------
+    def packed_layout(self, lp, c, head_dim, chunks, device):
+        """Where every head of a [Lp, C] tensor goes so that each head chunk's all-to-all send image [P, Lp, w] is contiguous:
+        returns (numel of the flat buffer, head_map int64 [H, 2] = (element offset of the head's row 0, row stride),
+        [(offset, w)] per chunk).  chunks: [(c0, c1)] column ranges inside a rank's head group, covering it."""
+        P = self.size
+        g = c // P  # columns of one rank's head group
+        key = (lp, c, head_dim, tuple(chunks), str(device))
+        cache = self.__dict__.setdefault("_layouts", {})
+        if key not in cache:
+            assert sorted(chunks) == list(chunks) and chunks[0][0] == 0 and chunks[-1][1] == g and \
+                all(a[1] == b[0] for a, b in zip(chunks, chunks[1:])), "chunks must tile the head group"
+            rows = []
+            for h in range(c // head_dim):
+                r, cc = divmod(h * head_dim, g)
+                c0, c1 = next(ch for ch in chunks if ch[0] <= cc < ch[1])
+                w = c1 - c0
+                rows.append((P * lp * c0 + r * lp * w + (cc - c0), w))
+            cache[key] = (lp * c, torch.tensor(rows, dtype=torch.int64, device=device), [(P * lp * c0, c1 - c0) for c0, c1 in chunks])
+        return cache[key]
+
+    def scatter_packed(self, flat, lp, off, w, async_op=False):
+        """The all-to-all of one chunk whose send image already sits at flat[off : off + P*Lp*w] as [P, Lp, w]."""
+        P = self.size
+        send = flat[off:off + P * lp * w].view(P, lp, w)
+        recv = torch.empty_like(send)
+        work = dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)
+        post = lambda r: r.view(P * lp, w)  # noqa: E731
+        return _Pending(work, recv, post) if async_op else post(recv)
+
     def gather_heads(self, x, async_op=False, out=None, cols=None):
         """[P*Lp, w] -> [Lp, P*w]: inverse of scatter_heads.  With `out` ([Lp, C]) and `cols` the chunk lands in columns
         c0..c1 of every head group of `out` (which is returned)."""

@@ -29,6 +29,36 @@ def rmsnorm_rope_(x, weight, rope, head_dim, rows_per_batch=None, eps=1e-6, out=
     return out
 
 
+def rmsnorm_rope_scatter(x, weight, rope, head_dim, out, head_map, rows_per_batch=None, eps=1e-6):
+    """rmsnorm_rope_ with the store scattered per head: head h of row r -> out.view(-1)[head_map[h, 0] + r * head_map[h, 1] + ...]
+    (elements).  `out` is a flat buffer holding the Ulysses send images (SeqParallel.packed_layout); x is left untouched."""
+    _C.check_gpu("x", x)
+    _C.check_contig("x", x)
+    _C.check_gpu("out", out)
+    _C.check_contig("out", out)
+    _C.check_gpu("head_map", head_map)
+    _C.check_dtype("head_map", head_map, torch.int64)
+    _C.check_contig("head_map", head_map)
+    rows, cols = x.shape
+    _C.check_shape("head_map", head_map, cols // head_dim, 2)
+    if out.numel() < rows * cols:
+        raise RuntimeError("rmsnorm_rope_scatter: out is smaller than the row-major image")
+    if weight is not None:
+        _C.check_dtype("weight", weight, torch.float32)
+        _C.check_shape("weight", weight, cols)
+    positions = 0
+    if rope is not None:
+        _C.check_dtype("rope", rope, torch.float32)
+        _C.check_contig("rope", rope)
+        if rope.dim() != 3 or rope.shape[1] != head_dim // 2 or rope.shape[2] != 2:
+            raise RuntimeError(f"rope must have shape (positions, {head_dim // 2}, 2)")
+        positions = rope.shape[0]
+    with torch.cuda.device(x.device):
+        _C.call("wanq_rmsnorm_rope_scatter", _C.ptr(x), _C.dt(x), _C.ptr(weight), _C.ptr(rope), _C.ptr(out), _C.dt(out),
+                _C.ptr(head_map), rows, cols, head_dim, rows_per_batch or rows, positions, float(eps), _C.stream())
+    return out
+
+
 class Q8Rows:
     """Per-(token, head) int8 form of a q or k tensor for the int8 Q.K^T attention: codes int8 [rows, C] and the fp32 scale
     planes [2, H, stride] (delta, -12582912 * delta) that wanq_rmsnorm_rope_q8 writes."""

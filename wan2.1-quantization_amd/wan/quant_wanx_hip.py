@@ -337,19 +337,23 @@ class WanAttentionBlockWithHipKernel(nn.Module):
             v = self._linear(sa.v, h)
             o = ops.attention(q, k, v, H, seq_len)
         else:
-            ops.rmsnorm_rope_(q, sa.norm_q_weight, rope, d, eps=self.eps)
             # Ulysses, pipelined over head chunks: this rank's H/P heads are split in two; the exchange of chunk 1 (and the
             # way back of chunk 0) flies under the attention of the other chunk, so about half of the all-to-all time of a
             # block hides behind its 2-6 ms of attention.  The collectives run in issue order on the group's own stream.
-            chunks = [(a * d, b * d) for a, b in _head_chunks(H // sp.size, q.shape[0] * sp.size, q.device)]
-            pend = [[sp.scatter_heads(q, async_op=True, cols=chunks[0])]]      # chunk 0 of q flies under the k GEMM
+            # RMSNorm+RoPE writes q and k straight into the send images of the chunks ([P, Lp, w] each): no pack pass.
+            lp, C = q.shape
+            chunks = [(a * d, b * d) for a, b in _head_chunks(H // sp.size, lp * sp.size, q.device)]
+            _, hmap, where = sp.packed_layout(lp, C, d, chunks, q.device)
+            qs = ops.rmsnorm_rope_scatter(q, sa.norm_q_weight, rope, d, torch.empty(lp * C, dtype=q.dtype, device=q.device), hmap, eps=self.eps)
+            pend = [[sp.scatter_packed(qs, lp, *where[0], async_op=True)]]        # chunk 0 of q flies under the k GEMM
             k = self._linear(sa.k, h)
-            ops.rmsnorm_rope_(k, sa.norm_k_weight, rope, d, eps=self.eps)
-            pend[0].append(sp.scatter_heads(k, async_op=True, cols=chunks[0]))  # ... of k under the v GEMM
+            ks = ops.rmsnorm_rope_scatter(k, sa.norm_k_weight, rope, d, torch.empty(lp * C, dtype=k.dtype, device=k.device), hmap, eps=self.eps)
+            pend[0].append(sp.scatter_packed(ks, lp, *where[0], async_op=True))   # ... of k under the v GEMM
             v = self._linear(sa.v, h)
             pend[0].append(sp.scatter_heads(v, async_op=True, cols=chunks[0]))
-            for cw in chunks[1:]:
-                pend.append([sp.scatter_heads(t, async_op=True, cols=cw) for t in (q, k, v)])
+            for cw, wh in zip(chunks[1:], where[1:]):
+                pend.append([sp.scatter_packed(qs, lp, *wh, async_op=True), sp.scatter_packed(ks, lp, *wh, async_op=True),
+                             sp.scatter_heads(v, async_op=True, cols=cw)])
             o = torch.empty_like(q)
             back = []
             for (c0, c1), (wq, wk, wv) in zip(chunks, pend):
