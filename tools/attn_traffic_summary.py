@@ -2,7 +2,7 @@
 """rocprofv3 counter CSVs of tools/attn_once.py -> profiles/*_attention_traffic.{csv,json} (same conventions as
 tools/gemm_traffic_summary.py: FETCH_SIZE KiB x2 on gfx950, WRITE_SIZE KiB).
 
-usage: attn_traffic_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out prefix>"""
+usage: attn_traffic_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out prefix> [code tag]"""
 import csv
 import json
 import os
@@ -30,6 +30,9 @@ def main():
         wtr.writerows(rows)
     summary = {"kernel": "attn_fwd_kernel", "launches": len(LAUNCHES), "hbm_bytes_per_launch": tot_hbm / len(LAUNCHES),
                "algorithmic_bytes_per_launch": tot_alg / len(LAUNCHES),
+               # which bench.py workload the launches belong to (bench.py reports the figure only for that workload) and which
+               # code they were taken on
+               "workload": "t2v-1.3B 832*480 81f n1", "code": sys.argv[4] if len(sys.argv) > 4 else "unknown",
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/attn_once.py, FETCH_SIZE x2 "
                          "(gfx950), KiB units; one self-attention + one cross-attention launch of a cfg-B block"}
     json.dump(summary, open(pre + ".json", "w"), indent=1)

@@ -3,7 +3,7 @@
 bench.py reports as roofline.traffic.  FETCH_SIZE is in KiB and needs the x2 gfx950 correction
 (/opt/skills/guides/MI355X_MICROARCH.md, HBM / rocprofv3 section); WRITE_SIZE is in KiB.
 
-usage: gemm_traffic_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out prefix>"""
+usage: gemm_traffic_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out prefix> [code tag]"""
 import csv
 import json
 import os
@@ -42,6 +42,9 @@ def main():
         wtr.writerows(out_rows)
     summary = {"kernel": "gemm_w8a8_big_kernel", "launches": len(LAUNCHES),
                "hbm_bytes_per_launch": tot_hbm / len(LAUNCHES), "algorithmic_bytes_per_launch": tot_alg / len(LAUNCHES),
+               # which bench.py workload the launches belong to (bench.py reports the figure only for that workload) and which
+               # code they were taken on
+               "workload": "t2v-1.3B 832*480 81f n1", "code": sys.argv[4] if len(sys.argv) > 4 else "unknown",
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/gemm_block_shapes.py, "
                          "FETCH_SIZE x2 (gfx950), KiB units; the ten GEMMs of one cfg-B block"}
     json.dump(summary, open(pre + ".json", "w"), indent=1)

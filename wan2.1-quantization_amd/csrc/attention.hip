@@ -14,7 +14,8 @@
 //                      register->key permutation 8(j>>2)+4h+(j&3) is matched by the order in which the A
 //                      operand V^T is gathered with ds_read_b64_tr_b16), so P never touches LDS.
 // K and V tiles travel global -> LDS by LDS-DMA (global_load_lds_dwordx4) into a ring of three 32-KiB stages, two
-// tiles ahead of the math, published by a counted s_waitcnt vmcnt(4) + one bare s_barrier per tile (DMA = true, the
+// tiles ahead of the math, published by a counted s_waitcnt vmcnt(N) (N = the pieces this wave issued for the tile after:
+// 8 for the issuing waves, 0 for the others; AT_WAIT_TILE_AHEAD) + one bare s_barrier per tile (DMA = true, the
 // default; +2.8 % over the register-staged two-stage form, DMA = false, kept behind WANQ_ATTN_V1=1).  LDS rows are
 // 256 B with the 16-B chunk index XORed by ((row&3)<<2 | (row>>2)&3): conflict-free for the b128 row reads of K, the
 // transposed reads of V and the staging writes; the DMA writes lane-linearly, so it applies the swizzle on the
