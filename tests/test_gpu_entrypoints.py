@@ -50,3 +50,7 @@ def test_four_entry_points_chain(tmp_path, config):
     rel = lambda a, b: ((a - b).norm() / b.norm()).item()  # noqa: E731
     print(f"{config}: kernel-mode vs fp {rel(hw, fp):.3e}; simulation-mode vs fp {rel(sim, fp):.3e}; kernel vs simulation {rel(hw, sim):.3e}")
     assert rel(hw, fp) < 0.05 and rel(sim, fp) < 0.05 and rel(hw, sim) < 0.03
+    if config == "config.yaml":  # the other solver of the reference's CLI (fm_solvers.py:69): runs, finite, a different trajectory
+        run("quant_generate.py", "--quant_config", qc, "--sample_solver", "dpm++", "--save_file", str(tmp_path / "dpm.pt"), cwd=tmp_path)
+        dpm = torch.load(tmp_path / "dpm.pt", weights_only=True)
+        assert dpm.shape == fp.shape and torch.isfinite(dpm).all() and not torch.equal(dpm, hw)
