@@ -104,6 +104,13 @@ int wanq_gemm_w8a8(const int8_t* a, const int8_t* w, void* out, int out_dtype, c
  *   over the stacked calls (ptq_wanx.py:336), the stack itself. */
 int wanq_col_absmax(const void* x, int x_dtype, float* colmax, int64_t rows, int cols, void* stream);
 
+/* v fake-quantisation of the reference's quantized attention (ViDiT-Q/examples/Wan2.1/models/quant_opensora.py:438-440:
+ * DynamicQuantizer over all tokens for every (head, channel)), on the token-major [rows, cols] tensor: per COLUMN c
+ *   delta_c = max(colmax[c] / (2^(b-1) - 1), 1e-6),   out = clamp(rne(x / delta_c), -2^(b-1), 2^(b-1) - 1) * delta_c.
+ * colmax: fp32 [cols] from wanq_col_absmax over the same rows.  In place (out == x) is allowed. */
+int wanq_fake_quant_cols(const void* x, int x_dtype, const float* colmax, void* out, int out_dtype, int n_bits,
+                         int64_t rows, int cols, void* stream);
+
 /* Per-row min / max / absmax of a weight matrix (StaticQuantizer.init_quant_params statistics,
  *   quant_utils/qdiff/base/base_quantizer.py:70-90).  Any of the outputs may be NULL. */
 int wanq_row_minmax(const void* w, int w_dtype, float* row_min, float* row_max, float* row_absmax,

@@ -123,6 +123,14 @@ def qk_fake_quant(x, n_bits=8):
     return dyn_fake_quant(x.reshape(L * n, d), n_bits).reshape(L, n, d)
 
 
+def v_fake_quant(v, n_bits=8):
+    """The reference's v quantisation for quantized attention: DynamicQuantizer over ALL TOKENS for every (head, channel) --
+    `self.v_quantizer(v.permute([0,1,3,2]).reshape([-1, N_token]))` (W/models/quant_opensora.py:438-440).
+    v [L, n, d] fp32 -> fake-quantised fp32."""
+    L, n, d = v.shape
+    return dyn_fake_quant(v.reshape(L, n * d).t().contiguous(), n_bits).t().reshape(L, n, d)
+
+
 def attention_qk_quant(q, k, v, k_len=None, n_bits=8):
     """attention() on fake-quantised q and k (post-RoPE, pre-scale, as the reference places the quantizers)."""
     return attention(qk_fake_quant(q, n_bits), qk_fake_quant(k, n_bits), v, k_len)
@@ -131,9 +139,11 @@ def attention_qk_quant(q, k, v, k_len=None, n_bits=8):
 class BlockRef:
     """One WanAttentionBlock in simulation mode.  `lin` maps 'self_attn.q' ... 'ffn.2' to callables."""
 
-    def __init__(self, lin, norm_w, modulation, num_heads, eps=1e-6, norm3=None, qk_bits=None, cross_qk_bits=None):
+    def __init__(self, lin, norm_w, modulation, num_heads, eps=1e-6, norm3=None, qk_bits=None, cross_qk_bits=None, v_bits=None,
+                 cross_v_bits=None):
         self.lin, self.norm_w, self.mod, self.n, self.eps, self.norm3 = lin, norm_w, modulation.float(), num_heads, eps, norm3
         self.qk_bits, self.cross_qk_bits = qk_bits, cross_qk_bits  # None = FP attention (the reference's Wan wiring)
+        self.v_bits, self.cross_v_bits = v_bits, cross_v_bits
 
     def __call__(self, x, e0, grid, seq_len, context, freqs):
         """x [L, C], e0 [1, 6, C], context [Lc, C] -> x' [L, C]   (model.py:293-370 for B = 1)."""
@@ -148,6 +158,8 @@ class BlockRef:
         q, k = rope_apply(q, grid, freqs), rope_apply(k, grid, freqs)
         if self.qk_bits:
             q, k = qk_fake_quant(q, self.qk_bits), qk_fake_quant(k, self.qk_bits)
+        if self.v_bits:
+            v = torch.cat([v_fake_quant(v[:seq_len], self.v_bits), v[seq_len:]])
         o = attention(q, k, v, seq_len).reshape(L, C)
         x = x + self.lin["self_attn.o"](o) * e[2]
         h = layer_norm(x, self.eps, *(self.norm3 or (None, None)))
@@ -156,6 +168,8 @@ class BlockRef:
         v = self.lin["cross_attn.v"](context).view(-1, n, d)
         if self.cross_qk_bits:
             q, k = qk_fake_quant(q, self.cross_qk_bits), qk_fake_quant(k, self.cross_qk_bits)
+        if self.cross_v_bits:
+            v = v_fake_quant(v, self.cross_v_bits)
         x = x + self.lin["cross_attn.o"](attention(q, k, v).reshape(L, C))
         h = layer_norm(x, self.eps) * (1 + e[4]) + e[3]
         y = self.lin["ffn.2"](F.gelu(self.lin["ffn.0"](h), approximate="tanh"))
@@ -166,7 +180,8 @@ LINEARS = ("self_attn.q", "self_attn.k", "self_attn.v", "self_attn.o", "cross_at
            "cross_attn.o", "ffn.0", "ffn.2")
 
 
-def block_from_state(sd, num_heads, eps=1e-6, quant=True, w_bits=8, a_bits=8, vidit=None, qk_bits=None, cross_qk_bits=None):
+def block_from_state(sd, num_heads, eps=1e-6, quant=True, w_bits=8, a_bits=8, vidit=None, qk_bits=None, cross_qk_bits=None,
+                     v_bits=None, cross_v_bits=None):
     """Build a BlockRef from a WanAttentionBlock state dict (CPU tensors).
     vidit: optional {linear name: (channel_mask fp32 [K], rotation fp64 [K,K])}."""
     lin = {}
@@ -179,4 +194,4 @@ def block_from_state(sd, num_heads, eps=1e-6, quant=True, w_bits=8, a_bits=8, vi
             lin[name] = FpLinear(w, b)
     norm_w = {k: sd[k + ".weight"].float() for k in ("self_attn.norm_q", "self_attn.norm_k", "cross_attn.norm_q", "cross_attn.norm_k")}
     norm3 = (sd["norm3.weight"].float(), sd["norm3.bias"].float()) if "norm3.weight" in sd else None
-    return BlockRef(lin, norm_w, sd["modulation"], num_heads, eps, norm3, qk_bits, cross_qk_bits)
+    return BlockRef(lin, norm_w, sd["modulation"], num_heads, eps, norm3, qk_bits, cross_qk_bits, v_bits, cross_v_bits)

@@ -141,3 +141,69 @@ def test_kernel_mode_block_with_quantized_qk_vs_oracle():
     err = rel_err(out, ref)
     print(f"block with int8 Q.K^T: rel err vs recipe oracle {err:.2e}; recipe vs FP-attention oracle {rel_err(ref, ref_noqk):.2e}")
     assert err < 1e-2
+
+
+@pytest.mark.parametrize("rows,cols,dtype,bits", [(777, 1536, torch.float32, 8), (300, 640, torch.bfloat16, 8), (64, 128, torch.float32, 4),
+                                                  (1, 8, torch.float32, 8)])
+def test_v_fake_quant_per_column_vs_oracle(rows, cols, dtype, bits):
+    """attn.v: DynamicQuantizer over all tokens for every (head, channel) (W/models/quant_opensora.py:438-440)."""
+    import viditq_extension.fused as fused
+
+    g = torch.Generator().manual_seed(rows + cols)
+    v = (torch.randn(rows, cols, generator=g) * torch.exp(torch.randn(cols, generator=g))).to(dtype)
+    v[:, 3] = 0  # an all-zero channel: eps rule
+    heads = max(1, cols // 128)
+    ref = wr.v_fake_quant(v.float().view(rows, heads, cols // heads), bits).reshape(rows, cols)
+    out, colmax = fused.fake_quant_cols_(v.to(DEV).clone(), bits)
+    np.testing.assert_array_equal(colmax.cpu().numpy(), v.float().abs().amax(0).numpy())
+    if dtype == torch.float32:
+        np.testing.assert_array_equal(out.cpu().numpy(), ref.numpy())  # bit-exact: IEEE division, rne, fp32 product
+    else:
+        np.testing.assert_array_equal(out.float().cpu().numpy(), ref.to(dtype).float().numpy())
+    assert out[:, 3].abs().max().item() == 0
+
+
+def test_kernel_mode_block_with_quantized_v_vs_oracle(tmp_path):
+    """attn.v / cross_attn.v (+ qk) through the quant config: block vs the simulation oracle with the same recipe; attn_map is
+    refused with the reason."""
+    from test_gpu_block import make_block, rel_err
+    from wan import ops
+    from wan.quant_wanx_hip import WanAttentionBlockWithHipKernel, _FpSrc
+
+    dim, ffn, heads, grid, lc = 512, 1024, 4, (2, 6, 8), 64
+    blk = make_block(dim, ffn, heads, 0)
+    sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    n_tok = grid[0] * grid[1] * grid[2]
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n_tok, dim, generator=g)
+    e0 = torch.randn(1, 6, dim, generator=g) * 0.3
+    ctx = torch.randn(lc, dim, generator=g)
+    freqs = wr.rope_freqs(dim // heads)
+    ref = wr.block_from_state(sd, heads, quant=True, v_bits=8, cross_v_bits=8)(x, e0, grid, n_tok, ctx, freqs)
+    ref_fp_v = wr.block_from_state(sd, heads, quant=True)(x, e0, grid, n_tok, ctx, freqs)
+    hb = WanAttentionBlockWithHipKernel.from_float(blk.to(DEV), attn_v_bits=8, cross_attn_v_bits=8)
+    out = hb(x.to(DEV).clone(), e0.to(DEV), ops.rope_table(freqs, grid, DEV), n_tok, _FpSrc(ctx.to(DEV), torch.bfloat16)).float().cpu()
+    err = rel_err(out, ref)
+    print(f"block with quantised v: rel err vs recipe oracle {err:.2e}; recipe vs FP-v oracle {rel_err(ref, ref_fp_v):.2e}")
+    assert err < 1e-2
+
+    # the config surface: attn.v is picked up by hardware_forward_refactor, attn.attn_map raises with the reason
+    from qdiff import config as qcfg
+    from wan.modules.model import WanModel
+    from wan.quant_wanx import QuantWanModel
+
+    base = {"model": {"model_id": "wan2.1", "model_type": "wanx"}, "remain_fp_regex": "text_embedding|time_embedding|time_projection|head\\.head",
+            "weight": {"n_bits": 8, "sym": False}, "act": {"n_bits": 8, "sym": True}}
+    torch.manual_seed(0)
+    with torch.device(DEV):
+        fp = WanModel(dim=256, ffn_dim=512, num_heads=2, num_layers=1, text_dim=64, freq_dim=64).eval()
+    m = QuantWanModel.from_float(fp, qcfg.create(dict(base, attn={"v": {"n_bits": 8, "sym": True}, "qk": {"n_bits": 8, "sym": True}})))
+    m.quant_layer_refactor()
+    m.set_init_done()
+    m.hardware_forward_refactor()
+    assert m.hip_blocks[0].attn_v_bits == 8 and m.hip_blocks[0].attn_qk8 and m.hip_blocks[0].cross_attn_v_bits is None
+    m2 = QuantWanModel.from_float(fp, qcfg.create(dict(base, attn={"attn_map": {"n_bits": 8, "group": "column"}})))
+    m2.quant_layer_refactor()
+    m2.set_init_done()
+    with pytest.raises(NotImplementedError, match="attention map"):
+        m2.hardware_forward_refactor()

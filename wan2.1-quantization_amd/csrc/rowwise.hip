@@ -532,6 +532,48 @@ extern "C" int wanq_col_absmax(const void* x, int x_dtype, float* colmax, int64_
   return check_launch("wanq_col_absmax");
 }
 
+// v fake-quantisation of the reference's quantized attention: DynamicQuantizer over ALL TOKENS for every (head, channel) --
+// `self.v_quantizer(v.permute([0,1,3,2]).reshape([-1, N_token]))`, ViDiT-Q/examples/Wan2.1/models/quant_opensora.py:438-440 --
+// i.e. per COLUMN of the token-major [tokens, heads*head_dim] tensor: delta_c = max(absmax_c / n, 1e-6), n = 2^(b-1) - 1,
+// y = clamp(rne(x / delta_c), -n-1, n) * delta_c.  colmax comes from wanq_col_absmax over the same rows.
+namespace wanq {
+__global__ __launch_bounds__(256) void fake_quant_cols_kernel(const void* x, int x_dt, const float* colmax, void* out, int out_dt,
+                                                              float nlev, int64_t rows, int cols) {
+  const int cpr = cols / 8;
+  const int64_t total = rows * (int64_t)cpr;
+  for (int64_t ch = (int64_t)blockIdx.x * 256 + threadIdx.x; ch < total; ch += (int64_t)gridDim.x * 256) {
+    const int64_t row = ch / cpr;
+    const int c0 = (int)(ch - row * cpr) * 8;
+    float v[8], m[8];
+    load8_rt(x, x_dt, row * cols + c0, v);
+    Io<F32>::load8(colmax, c0, m);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float d = m[j] / nlev;
+      if (d < 1e-6f) d = 1e-6f;
+      v[j] = __builtin_amdgcn_fmed3f(rintf(v[j] / d), -nlev - 1.f, nlev) * d;
+    }
+    store8_rt(out, out_dt, row * cols + c0, v);
+  }
+}
+}  // namespace wanq
+
+extern "C" int wanq_fake_quant_cols(const void* x, int x_dtype, const float* colmax, void* out, int out_dtype, int n_bits,
+                                    int64_t rows, int cols, void* stream) {
+  WANQ_REQUIRE(x && colmax && out, WANQ_E_ARG, "wanq_fake_quant_cols: NULL pointer");
+  WANQ_REQUIRE(is_fp(x_dtype) && is_fp(out_dtype), WANQ_E_ARG, "wanq_fake_quant_cols: bad dtype code");
+  WANQ_REQUIRE(n_bits >= 2 && n_bits <= 8, WANQ_E_ARG, "wanq_fake_quant_cols: n_bits=%d must be in [2, 8]", n_bits);
+  WANQ_REQUIRE(cols >= 8 && cols % 8 == 0, WANQ_E_SHAPE, "wanq_fake_quant_cols: cols=%d must be a multiple of 8", cols);
+  WANQ_REQUIRE(rows >= 0 && rows < (1ll << 40), WANQ_E_SHAPE, "wanq_fake_quant_cols: rows out of range");
+  if (rows == 0) return WANQ_OK;
+  const int64_t total = rows * (cols / 8);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(fake_quant_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, x_dtype, colmax, out,
+                     out_dtype, (float)((1 << (n_bits - 1)) - 1), rows, cols);
+  return check_launch("wanq_fake_quant_cols");
+}
+
 extern "C" int wanq_row_minmax(const void* w, int w_dtype, float* row_min, float* row_max, float* row_absmax,
                                int64_t rows, int cols, void* stream) {
   WANQ_REQUIRE(w && (row_min || row_max || row_absmax), WANQ_E_ARG, "wanq_row_minmax: NULL pointer");

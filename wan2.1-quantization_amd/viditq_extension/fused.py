@@ -188,6 +188,18 @@ def col_absmax_(running_max, x):
     return running_max
 
 
+def fake_quant_cols_(x, n_bits=8, colmax=None):
+    """In place: every column of x [rows, cols] fake-quantised with its own dynamic symmetric scale over all rows (the v recipe of
+    the reference's quantized attention: per (head, channel) over all tokens).  Returns (x, colmax)."""
+    rows, cols = _rows_cols("x", x)
+    if colmax is None:
+        colmax = torch.zeros(cols, dtype=torch.float32, device=x.device)
+        col_absmax_(colmax, x)
+    with torch.cuda.device(x.device):
+        _C.call("wanq_fake_quant_cols", _C.ptr(x), _C.dt(x), _C.ptr(colmax), _C.ptr(x), _C.dt(x), int(n_bits), rows, cols, _C.stream())
+    return x, colmax
+
+
 def row_minmax(w):
     """(min, max, absmax) per row of a 2-D weight, fp32."""
     rows, cols = _rows_cols("w", w)

@@ -254,13 +254,17 @@ class _Attn(nn.Module):
 
 
 class WanAttentionBlockWithHipKernel(nn.Module):
-    def __init__(self, dim, ffn_dim, num_heads, eps=1e-6, act_dtype=torch.bfloat16, attn_qk8=False, cross_attn_qk8=False):
+    def __init__(self, dim, ffn_dim, num_heads, eps=1e-6, act_dtype=torch.bfloat16, attn_qk8=False, cross_attn_qk8=False,
+                 attn_v_bits=None, cross_attn_v_bits=None):
         super().__init__()
         self.dim, self.ffn_dim, self.num_heads, self.head_dim, self.eps = dim, ffn_dim, num_heads, dim // num_heads, eps
         self.act_dtype = act_dtype
         # quant_config.attn.qk / cross_attn.qk (8-bit symmetric): q and k of that attention leave RMSNorm + RoPE as
         # per-(token, head) int8 codes and Q.K^T runs on the int8 matrix cores (Q/base/quant_attn.py:168-174)
         self.attn_qk8, self.cross_attn_qk8 = bool(attn_qk8), bool(cross_attn_qk8)
+        # quant_config.attn.v / cross_attn.v: v fake-quantised per (head, channel) over all tokens before the attention
+        # (W/models/quant_opensora.py:438-440); P.V itself stays bf16 -- the reference's recipe has no integer P either
+        self.attn_v_bits, self.cross_attn_v_bits = attn_v_bits, cross_attn_v_bits
         self.self_attn, self.cross_attn = _Attn(dim), _Attn(dim)
         self.ffn0 = self.ffn2 = None
         self.register_buffer("modulation", torch.zeros(1, 6, dim))
@@ -269,11 +273,13 @@ class WanAttentionBlockWithHipKernel(nn.Module):
         self.register_buffer("ones_gate", torch.ones(dim))
 
     @classmethod
-    def from_float(cls, blk, n_bits=8, sym=False, act_dtype=torch.bfloat16, attn_qk8=False, cross_attn_qk8=False):
+    def from_float(cls, blk, n_bits=8, sym=False, act_dtype=torch.bfloat16, attn_qk8=False, cross_attn_qk8=False,
+                   attn_v_bits=None, cross_attn_v_bits=None):
         """Build from a WanAttentionBlock (wan/modules/model.py) whose Linears are either plain nn.Linear
         (quantized here with plain per-channel W8 when n_bits is given, kept FP when n_bits is None) or qdiff
         QuantizedLinear variants (their codes / parameters / ViDiT transform are taken over as they are)."""
-        m = cls(blk.dim, blk.ffn_dim, blk.num_heads, blk.eps, act_dtype, attn_qk8, cross_attn_qk8).to(blk.modulation.device)
+        m = cls(blk.dim, blk.ffn_dim, blk.num_heads, blk.eps, act_dtype, attn_qk8, cross_attn_qk8, attn_v_bits,
+                cross_attn_v_bits).to(blk.modulation.device)
         for name in ("self_attn", "cross_attn"):
             src, dst = getattr(blk, name), getattr(m, name)
             for l in "qkvo":
@@ -311,6 +317,13 @@ class WanAttentionBlockWithHipKernel(nn.Module):
             return residual
         return y
 
+    @staticmethod
+    def _vq(v, n_bits, k_len):
+        """attn.v / cross_attn.v of the quant config: v fake-quantised in place, per column over the first k_len rows."""
+        if n_bits:
+            fused.fake_quant_cols_(v if k_len is None or k_len >= v.shape[0] else v[:k_len], n_bits)
+        return v
+
     def forward(self, x, e0, rope, seq_len, ctx, sp=None):
         """x: fp32 [L, C] residual stream (this rank's token shard under sequence parallelism), updated IN PLACE.
         e0: fp32 [1, 6, C].  rope: fp32 [pos, d/2, 2] for the local tokens.  seq_len: number of real (unpadded)
@@ -328,13 +341,13 @@ class WanAttentionBlockWithHipKernel(nn.Module):
             # (under sequence parallelism the exchange moves bf16 q / k; the int8 form is single-rank for now)
             q8 = ops.rmsnorm_rope_q8(q, sa.norm_q_weight, rope, d, False, eps=self.eps)
             k8 = ops.rmsnorm_rope_q8(self._linear(sa.k, h), sa.norm_k_weight, rope, d, True, eps=self.eps)
-            v = self._linear(sa.v, h)
+            v = self._vq(self._linear(sa.v, h), self.attn_v_bits, seq_len)
             o = ops.attention_qk8(q8, k8, v, H, seq_len)
         elif sp is None or sp.size == 1:
             ops.rmsnorm_rope_(q, sa.norm_q_weight, rope, d, eps=self.eps)
             k = self._linear(sa.k, h)
             ops.rmsnorm_rope_(k, sa.norm_k_weight, rope, d, eps=self.eps)
-            v = self._linear(sa.v, h)
+            v = self._vq(self._linear(sa.v, h), self.attn_v_bits, seq_len)
             o = ops.attention(q, k, v, H, seq_len)
         else:
             # Ulysses, pipelined over head chunks: this rank's H/P heads are split in two; the exchange of chunk 1 (and the
@@ -357,7 +370,8 @@ class WanAttentionBlockWithHipKernel(nn.Module):
             o = torch.empty_like(q)
             back = []
             for (c0, c1), (wq, wk, wv) in zip(chunks, pend):
-                oc = ops.attention(wq.wait(), wk.wait(), wv.wait(), (c1 - c0) // d, seq_len)
+                # (v of this rank's heads, all tokens: the per-(head, channel) statistics are local after the exchange)
+                oc = ops.attention(wq.wait(), wk.wait(), self._vq(wv.wait(), self.attn_v_bits, seq_len), (c1 - c0) // d, seq_len)
                 back.append(sp.gather_heads(oc, async_op=True, out=o, cols=(c0, c1)))
             for b in back:
                 b.wait()
@@ -367,7 +381,7 @@ class WanAttentionBlockWithHipKernel(nn.Module):
         h = _LnSrc(self, x, self.norm3_weight, self.norm3_bias.view(1, -1), None)
         q = self._linear(ca.q, h)
         k = self._linear(ca.k, ctx)
-        v = self._linear(ca.v, ctx)
+        v = self._vq(self._linear(ca.v, ctx), self.cross_attn_v_bits, None)
         if self.cross_attn_qk8:
             o = ops.attention_qk8(ops.rmsnorm_rope_q8(q, ca.norm_q_weight, None, d, False, eps=self.eps),
                                   ops.rmsnorm_rope_q8(k, ca.norm_k_weight, None, d, True, eps=self.eps), v, H)
