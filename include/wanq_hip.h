@@ -260,8 +260,8 @@ int wanq_gemm_w4a8(const int8_t* a, const uint8_t* w_packed, void* out, int out_
  * alias inputs element for element).  Classifier-free guidance, the model-output conversion and the UniPC / DPM++ / Euler
  * predictor and corrector are all such combinations (ViDiT-Q/examples/Wan2.1/wan/text2video.py:260-269,
  * wan/utils/fm_solvers_unipc.py:303-307,354-630): one launch replaces the ~12 elementwise torch kernels of a step.
- * coef: DEVICE fp32 [n_out][n_in] (refreshed per step by an async copy, so the launch can live in a captured HIP graph). */
-int wanq_lincomb(int n_out, int n_in, const float* coef_dev, const float* const* in, float* const* out, int64_t numel,
+ * coef: HOST fp32 [n_out][n_in], copied into the kernel arguments by this call (the launch does not read it afterwards). */
+int wanq_lincomb(int n_out, int n_in, const float* coef, const float* const* in, float* const* out, int64_t numel,
                  void* stream);
 
 #ifdef __cplusplus

@@ -54,3 +54,34 @@ def test_four_entry_points_chain(tmp_path, config):
         run("quant_generate.py", "--quant_config", qc, "--sample_solver", "dpm++", "--save_file", str(tmp_path / "dpm.pt"), cwd=tmp_path)
         dpm = torch.load(tmp_path / "dpm.pt", weights_only=True)
         assert dpm.shape == fp.shape and torch.isfinite(dpm).all() and not torch.equal(dpm, hw)
+
+
+def test_four_entry_points_at_headline_size(tmp_path):
+    """The same chain at BASELINE config 2's size -- all 30 blocks, 832x480x81f (L = 32760), W8A8 on all 300 Linears with the
+    ViDiT transform on q / k / v -- for 3 UniPC steps: the quantized kernel-mode latent after the whole loop stays within 5e-2
+    of the FP run's, artefacts have the full-size shapes, and kernel mode loads the exported integer checkpoint."""
+    qc = os.path.join(PKG, "quant_configs", "w8a8_all_linears.yaml")
+    calib = str(tmp_path / "calib.pth")
+
+    def run_full(script, *args):
+        cmd = [sys.executable, os.path.join(PKG, script), "--task", "t2v-1.3B", "--size", "832*480", "--frame_num", "81", "--sample_steps", "3",
+               "--base_seed", "42", "--output_dir", str(tmp_path), *args]
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp_path, timeout=900)
+        assert r.returncode == 0, f"{script} failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+        return r.stdout + r.stderr
+
+    run_full("fp_generate.py")
+    fp = torch.load(tmp_path / "fp_latent_0.pt", weights_only=True).float()
+    assert fp.shape == (16, 21, 60, 104) and torch.isfinite(fp).all()
+    run_full("get_calib_data_wanx.py", "--quant_config", qc, "--calib_data", calib)
+    cd = torch.load(calib, weights_only=True)
+    assert len([k for k in cd if k.startswith("blocks.")]) == 300 and cd["blocks.29.ffn.2"].shape[-1] == 8960
+    run_full("ptq_wanx.py", "--quant_config", qc, "--calib_data", calib)
+    iw = torch.load(tmp_path / "checkpoint" / "int_weight.pt", weights_only=True)
+    assert iw["blocks.29.ffn.0.weight"].shape == (8960, 1536) and iw["blocks.29.ffn.0.weight"].dtype == torch.int8
+    log = run_full("quant_generate.py", "--quant_config", qc)
+    q = torch.load(tmp_path / "quant_latent_0.pt", weights_only=True).float()
+    rel = ((q - fp).norm() / fp.norm()).item()
+    print(f"headline size, 3 steps: quantized kernel mode vs FP rel L2 {rel:.3e}")
+    assert q.shape == fp.shape and torch.isfinite(q).all() and rel < 5e-2
+    assert "int_weight" in log  # the kernel-mode blocks were loaded from the exported checkpoint

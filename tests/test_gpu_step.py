@@ -16,18 +16,18 @@ def test_lincomb_kernel_vs_definition():
     for n_out, n_in, numel in [(1, 1, 4), (3, 6, 16 * 21 * 60 * 104), (4, 8, 1000)]:
         ins = [torch.randn(numel, device=DEV, generator=g) for _ in range(n_in)]
         outs = [torch.empty(numel, device=DEV) for _ in range(n_out)]
-        coef = torch.randn(n_out, n_in, device=DEV, generator=g)
-        lincomb(coef, ins, outs)
+        coef = torch.randn(n_out, n_in)  # host coefficients: they travel by value with the launch
+        lincomb(coef.numpy(), ins, outs)
         for o in range(n_out):
             ref = sum(coef[o, i].double() * ins[i].double() for i in range(n_in))
             assert float((outs[o].double() - ref).abs().max()) < 1e-5 * float(ref.abs().max() + 1)
     # an output may alias an input element for element
     a, b = torch.randn(4096, device=DEV, generator=g), torch.randn(4096, device=DEV, generator=g)
     want = 2.0 * a - 0.5 * b
-    lincomb(torch.tensor([[2.0, -0.5]], device=DEV), [a, b], [a])
+    lincomb([[2.0, -0.5]], [a, b], [a])
     torch.testing.assert_close(a, want, rtol=1e-6, atol=1e-6)
     with pytest.raises(RuntimeError):
-        lincomb(coef, [torch.zeros(6, device=DEV)], [torch.zeros(6, device=DEV)])  # numel % 4
+        lincomb([[1.0]], [torch.zeros(6, device=DEV)], [torch.zeros(6, device=DEV)])  # numel % 4
 
 
 @pytest.mark.parametrize("solver", ["unipc", "dpm++", "euler"])
@@ -52,6 +52,36 @@ def test_fused_step_on_gpu_equals_plain_scheduler(solver):
         xb = f.step(c, u, xb, t)
         assert float((xa - xb).abs().max() / xa.abs().max()) < 2e-6
     assert f.n_launch == 12
+
+
+def test_fused_step_with_the_cpu_running_steps_ahead_of_the_gpu():
+    """In the real loop the CPU enqueues a whole step (~1400 launches, 0.5 s of GPU time) and is back in FusedStep.step long
+    before the GPU gets there.  Whatever carries the coefficients must not be reused before the launch has consumed it (an
+    earlier form refreshed ONE pinned host buffer per step with an async copy: steps then ran with their successor's
+    coefficients -- found by the headline-size entry-point test).  Here ~30 ms of queued GPU work precede every fused step and
+    nothing synchronises until the end."""
+    from wan.utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
+    from wan.utils.fused_step import FusedStep
+
+    a, b = FlowUniPCMultistepScheduler(1000, shift=1.0), FlowUniPCMultistepScheduler(1000, shift=1.0)
+    a.set_timesteps(8, device=DEV, shift=5.0)
+    b.set_timesteps(8, device=DEV, shift=5.0)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(16, 21, 60, 104, device=DEV, generator=g)
+    cs = [torch.randn(x.shape, device=DEV, generator=g) for _ in range(8)]
+    us = [torch.randn(x.shape, device=DEV, generator=g) for _ in range(8)]
+    big = torch.randn(8192, 8192, device=DEV, dtype=torch.bfloat16)
+    xa = x.clone()
+    for i, t in enumerate(a.timesteps):
+        xa = a.step(us[i] + 5.0 * (cs[i] - us[i]), t, xa)
+    torch.cuda.synchronize()
+    f, xb = FusedStep(b, 5.0, like=x), x.clone()
+    for i, t in enumerate(b.timesteps):
+        for _ in range(24):
+            big @ big  # ~1.3 ms each: the GPU falls behind, the CPU does not wait
+        xb = f.step(cs[i], us[i], xb, t)
+    torch.cuda.synchronize()
+    assert float((xa - xb).abs().max() / xa.abs().max()) < 2e-6
 
 
 def test_graph_replay_of_the_dit_passes_is_bit_equal_to_eager():

@@ -110,8 +110,8 @@ def test_fused_step_equals_scheduler_for_all_solvers():
     from wan.utils.fm_solvers import FlowDPMSolverMultistepScheduler, FlowMatchScheduler
     from wan.utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
 
-    def definition(coef_dev, ins, outs):
-        c = coef_dev.view(-1)[:len(outs) * len(ins)].view(len(outs), len(ins))
+    def definition(coef, ins, outs):
+        c = torch.as_tensor(coef, dtype=torch.float32).reshape(len(outs), len(ins))
         for o in range(len(outs)):
             outs[o].copy_(sum(c[o, i] * ins[i] for i in range(len(ins))))
 

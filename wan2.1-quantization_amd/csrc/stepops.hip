@@ -2,8 +2,10 @@
 // (ViDiT-Q/examples/Wan2.1/wan/text2video.py:260-269; wan/utils/fm_solvers_unipc.py:303-307,354-630 -- every line of the
 // UniPC / DPM++ / Euler update is a linear combination of a handful of latent-sized tensors with scalar coefficients).
 //   out[o][e] = sum_i coef[o][i] * in[i][e]        o < n_out <= 4,  i < n_in <= 8,  fp32 tensors of `numel` elements
-// coef is DEVICE memory (fp32 [n_out][n_in], row-major): the host refreshes it with an async copy per step, so the launch can
-// sit inside a captured HIP graph whose replay sees the new coefficients.  HBM-bound: (n_in + n_out) * 4 B per element.
+// coef is HOST memory (fp32 [n_out][n_in], row-major) and travels BY VALUE in the kernel arguments: nothing the host does after
+// the call can change what the launch computes.  (An earlier form kept it in device memory refreshed by an async copy from one
+// pinned buffer per step; with the CPU a step ahead of the GPU the next step's coefficients overwrote the buffer before the copy
+// ran.)  HBM-bound: (n_in + n_out) * 4 B per element.
 #include "wanq_common.h"
 
 namespace wanq {
@@ -11,15 +13,13 @@ namespace wanq {
 struct LinParams {
   const float* in[8];
   float* out[4];
-  const float* coef;
+  float coef[32];
   int n_in, n_out;
   int64_t n4;  // numel / 4
 };
 
 __global__ __launch_bounds__(256) void lincomb_kernel(const LinParams p) {
-  __shared__ float c[32];
-  if (threadIdx.x < p.n_in * p.n_out) c[threadIdx.x] = p.coef[threadIdx.x];
-  __syncthreads();
+  const float* c = p.coef;  // kernel arguments: scalar loads
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.n4; i += (int64_t)gridDim.x * 256) {
     float4 acc[4];
 #pragma unroll
@@ -48,10 +48,10 @@ __global__ __launch_bounds__(256) void lincomb_kernel(const LinParams p) {
 
 using namespace wanq;
 
-extern "C" int wanq_lincomb(int n_out, int n_in, const float* coef_dev, const float* const* in, float* const* out, int64_t numel,
+extern "C" int wanq_lincomb(int n_out, int n_in, const float* coef, const float* const* in, float* const* out, int64_t numel,
                             void* stream) {
   WANQ_REQUIRE(n_out >= 1 && n_out <= 4 && n_in >= 1 && n_in <= 8, WANQ_E_ARG, "wanq_lincomb: n_out=%d (1..4), n_in=%d (1..8)", n_out, n_in);
-  WANQ_REQUIRE(coef_dev && in && out, WANQ_E_ARG, "wanq_lincomb: NULL pointer");
+  WANQ_REQUIRE(coef && in && out, WANQ_E_ARG, "wanq_lincomb: NULL pointer");
   WANQ_REQUIRE(numel >= 0 && numel % 4 == 0, WANQ_E_SHAPE, "wanq_lincomb: numel=%lld must be a multiple of 4", (long long)numel);
   if (numel == 0) return WANQ_OK;
   LinParams p{};
@@ -63,7 +63,8 @@ extern "C" int wanq_lincomb(int n_out, int n_in, const float* coef_dev, const fl
     WANQ_REQUIRE(out[o] && ((uintptr_t)out[o] & 15) == 0, WANQ_E_ARG, "wanq_lincomb: output %d is NULL or not 16-byte aligned", o);
     p.out[o] = out[o];
   }
-  p.coef = coef_dev; p.n_in = n_in; p.n_out = n_out; p.n4 = numel / 4;
+  for (int k = 0; k < n_out * n_in; ++k) p.coef[k] = coef[k];
+  p.n_in = n_in; p.n_out = n_out; p.n4 = numel / 4;
   const int64_t blocks = (p.n4 + 255) / 256;
   hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("wanq_lincomb");

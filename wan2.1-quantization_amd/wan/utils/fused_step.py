@@ -48,8 +48,11 @@ class LinForm:
         return len(nz) == 1 and self.c[nz[0]] == 1.0, (int(nz[0]) if len(nz) == 1 else -1)
 
 
-def lincomb(coef_dev, ins, outs):
-    """outs[o] = sum_i coef_dev[o, i] * ins[i]; fp32 contiguous tensors of equal numel; coef_dev fp32 [n_out, n_in] on the GPU."""
+def lincomb(coef, ins, outs):
+    """outs[o] = sum_i coef[o, i] * ins[i]; fp32 contiguous tensors of equal numel; coef: host fp32 [n_out, n_in] (numpy / torch
+    CPU / nested lists) -- it is copied into the kernel arguments by the call."""
+    import ctypes
+    c = np.ascontiguousarray(np.asarray(coef, dtype=np.float32).reshape(len(outs), len(ins)))
     n = ins[0].numel()
     for t in list(ins) + list(outs):
         _C.check_gpu("tensor", t)
@@ -58,7 +61,8 @@ def lincomb(coef_dev, ins, outs):
         if t.numel() != n:
             raise RuntimeError("lincomb: tensors must have the same number of elements")
     with torch.cuda.device(ins[0].device):
-        _C.call("wanq_lincomb", len(outs), len(ins), _C.ptr(coef_dev), _C.ptr_array(ins), _C.ptr_array(outs), n, _C.stream())
+        _C.call("wanq_lincomb", len(outs), len(ins), c.ctypes.data_as(ctypes.c_void_p), _C.ptr_array(ins), _C.ptr_array(outs), n,
+                _C.stream())
 
 
 class FusedStep:
@@ -75,9 +79,6 @@ class FusedStep:
 
     def __init__(self, sched, guide_scale, like):
         self.sched, self.g = sched, float(guide_scale)
-        dev = like.device
-        self.coef_host = torch.zeros(4, self.MAX_IN, dtype=torch.float32).pin_memory() if dev.type == "cuda" else None
-        self.coef_dev = torch.zeros(4, self.MAX_IN, dtype=torch.float32, device=dev)
         # output pool: rotated so that an output never aliases a live history tensor
         self.pool = [torch.empty_like(like, dtype=torch.float32) for _ in range(8)]
         self.n_launch = 0
@@ -129,14 +130,8 @@ class FusedStep:
         coef = np.zeros((4, self.MAX_IN), dtype=np.float32)
         for o, (_, f) in enumerate(todo):
             coef[o, :n] = f.c.astype(np.float32)
-        # the kernel reads coef as a dense [n_out][n_in] table
-        dense = torch.from_numpy(np.ascontiguousarray(coef[:len(todo), :n]).reshape(-1))
-        if self.coef_host is not None:
-            self.coef_host.view(-1)[:dense.numel()].copy_(dense)
-            self.coef_dev.view(-1)[:dense.numel()].copy_(self.coef_host.view(-1)[:dense.numel()], non_blocking=True)
-        else:
-            self.coef_dev.view(-1)[:dense.numel()].copy_(dense)
-        lincomb(self.coef_dev, [b.contiguous() for b in basis], outs)
+        # the coefficients go by value with the launch: the CPU may be steps ahead of the GPU
+        lincomb(coef[:len(todo), :n], [b.contiguous() for b in basis], outs)
         self.n_launch += 1
         for (key, _), t in zip(todo, outs):
             resolved[key] = t
