@@ -39,14 +39,15 @@ def test_two_ranks_ulysses_at_14b_block_dims():
     assert r.stdout.count("fsdp_rel=0.000e+00") == 2, r.stdout[-2000:]
 
 
-def test_bench_multi_rank_control_flow_rehearsal():
-    """bench.py --gpus 2 end to end (cfg-A frame count so that it takes seconds): rendezvous, parallel plan, calibration on
+@pytest.mark.parametrize("gpus,plan", [(2, "cfg2xsp1"), (4, "cfg2xsp2")])
+def test_bench_multi_rank_control_flow_rehearsal(gpus, plan):
+    """bench.py --gpus N end to end (cfg-A frame count so that it takes seconds): rendezvous, parallel plan, calibration on
     every rank, timed step with the cfg all-gather, max-over-ranks timing, one JSON line from rank 0."""
     import json
 
     root = os.path.dirname(HERE)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "0",
            "--frames", "9", "--no-cpu-baseline", "--no-quality"]
     env = dict(os.environ, OMP_NUM_THREADS="4", WANQ_BENCH_REHEARSE_ON_ONE_GPU="1")
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -54,5 +55,5 @@ def test_bench_multi_rank_control_flow_rehearsal():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "cfg2xsp1" and out["value"] > 0
+    assert out["n_gpus"] == gpus and out["config"]["parallelism"] == plan and out["value"] > 0 and out["config"]["rccl_ranks"] == gpus
     assert out["roofline"]["frac"] > 0 and "REHEARSAL" in out["data"]
