@@ -29,7 +29,7 @@ def _ulysses_worker(rank, world, port, q):
 
         sp = SeqParallel(None)
         assert sp.size == world and sp.rank == rank
-        H, d, L = 4, 8, 10 * world
+        H, d, L = max(4, world), 8, 10 * world
         g = torch.Generator().manual_seed(0)
         full = [torch.randn(L, H * d, generator=g) for _ in range(3)]
         lp = L // world
@@ -118,6 +118,11 @@ def test_ulysses_layout_and_attention_world2():
 
 def test_ulysses_layout_and_attention_world4():
     _run(_ulysses_worker, 4, 29612)
+
+
+def test_ulysses_layout_and_attention_world8():
+    """BASELINE config 4's Ulysses degree (14B: 40 heads over 8 ranks), on the layout code alone."""
+    _run(_ulysses_worker, 8, 29615)
 
 
 def test_cfg_x_sp_plan_world2():
