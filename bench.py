@@ -237,9 +237,12 @@ def main():
         if isinstance(mod, QuantizedLinear) and (mod.uses_mask or mod.uses_rotation):
             calib.init_rotation_and_channel_mask_(mod, name, calib_data, gen)
             n_vidit += 1
+    if quant_config.get("mixed_precision", None) is not None:  # BASELINE config 5: per-layer bit-widths by regex (quant_generate.py does the same)
+        model.bitwidth_refactor()
     model.set_init_done()
     model.hardware_forward_refactor()
     n_quant = sum(1 for m in model.modules() if isinstance(m, QuantizedLinear))
+    n_w4 = sum(1 for b in model.hip_blocks for m in b.modules() if getattr(m, "w_bits", 8) == 4)
     if world > 1 or args.no_quality:
         del fp
         torch.cuda.empty_cache()
@@ -303,11 +306,11 @@ def main():
 
     gs = timer.summary()
     out = {
-        "metric": "denoising steps/sec Wan2.1-%s W8A8 %sx%df" % (args.model.split("-")[-1], args.size.replace("*", "x"), args.frames), "value": args.steps / dt, "unit": "steps/s",
+        "metric": "denoising steps/sec Wan2.1-%s %s %sx%df" % (args.model.split("-")[-1], "W4A8-mixed" if n_w4 else "W8A8", args.size.replace("*", "x"), args.frames), "value": args.steps / dt, "unit": "steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "instrumented_ms_per_step": dt_prof / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
-        "config": {"workload": f"Wan2.1-{args.model} DiT, {n_quant} Linears W8A8 (W asym per-channel static, A sym per-token dynamic; "
+        "config": {"workload": f"Wan2.1-{args.model} DiT, {n_quant} Linears W8A8{f' of which {n_w4} W4A8 (packed 4-bit weights)' if n_w4 else ''} (W asym per-channel static, A sym per-token dynamic; "
                                f"ViDiT-Q scale+rotate alpha=0.5665 on {n_vidit} self-attn q/k/v layers), "
                                f"{args.size}x{args.frames}f, latent {list(shape)}, L={seq_len}, cond+uncond+CFG+scheduler per step",
                    "quant_config": args.quant_config, "attention": "bf16", "parallelism": plan.describe(),
