@@ -170,12 +170,17 @@ def main():
     ap.add_argument("--graph", type=int, default=int(os.environ.get("WANQ_BENCH_GRAPH", "0")), choices=[0, 1],
                     help="1 (single GPU only): the two DiT passes of a step are replayed from a captured HIP graph "
                          "(wan/graph.py); 0 (default): every kernel is launched eagerly -- measured the same (DESIGN.md 5): the host runs ahead")
-    ap.add_argument("--preset", default=os.environ.get("WANQ_BENCH_PRESET", ""), choices=["", "14B-ulysses"],
-                    help="14B-ulysses = the second north-star target: --model t2v-14B --size 1280*720 --no-cfg-parallel "
-                         "(Ulysses degree = N; also selectable with WANQ_BENCH_PRESET in the environment)")
+    ap.add_argument("--dit-fsdp", dest="dit_fsdp", action="store_true",
+                    help="N > 1: shard the kernel-mode blocks' integer weights over all ranks, gathered one block ahead (wan/distributed/fsdp.py)")
+    ap.add_argument("--preset", default=os.environ.get("WANQ_BENCH_PRESET", ""), choices=["", "14B-ulysses", "14B-w4a8-fsdp"],
+                    help="14B-ulysses = BASELINE config 4: --model t2v-14B --size 1280*720 --no-cfg-parallel (Ulysses degree = N); "
+                         "14B-w4a8-fsdp = BASELINE config 5: the same + --quant-config w4a8_mixed.yaml --dit-fsdp "
+                         "(also selectable with WANQ_BENCH_PRESET in the environment)")
     args = ap.parse_args()
-    if args.preset == "14B-ulysses":
+    if args.preset in ("14B-ulysses", "14B-w4a8-fsdp"):
         args.model, args.size, args.no_cfg_parallel = "t2v-14B", "1280*720", True
+    if args.preset == "14B-w4a8-fsdp":
+        args.quant_config, args.dit_fsdp = "w4a8_mixed.yaml", True
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -243,6 +248,9 @@ def main():
     model.hardware_forward_refactor()
     n_quant = sum(1 for m in model.modules() if isinstance(m, QuantizedLinear))
     n_w4 = sum(1 for b in model.hip_blocks for m in b.modules() if getattr(m, "w_bits", 8) == 4)
+    sharded = None
+    if args.dit_fsdp and world > 1:
+        sharded = model.shard_blocks(None)  # all ranks hold the same model: FULL_SHARD over the world
     if world > 1 or args.no_quality:
         del fp
         torch.cuda.empty_cache()
@@ -314,6 +322,8 @@ def main():
                                f"ViDiT-Q scale+rotate alpha=0.5665 on {n_vidit} self-attn q/k/v layers), "
                                f"{args.size}x{args.frames}f, latent {list(shape)}, L={seq_len}, cond+uncond+CFG+scheduler per step",
                    "quant_config": args.quant_config, "attention": "bf16", "parallelism": plan.describe(),
+                   "dit_fsdp": None if sharded is None else {"ranks": sharded.P, "block_weight_MB_per_rank": round(sharded.bytes_per_rank() / 1e6, 1),
+                                                             "of_MB": round(len(sharded.blocks) * sharded.full_bytes / 1e6, 1)},
                    "launch": "hip graph replay of the two DiT passes + 1 fused CFG/scheduler kernel" if graphed is not None else
                              "eager launches + 1 fused CFG/scheduler kernel",
                    "rccl_ranks": dist.get_world_size() if world > 1 else 1},

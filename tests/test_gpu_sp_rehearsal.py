@@ -39,8 +39,9 @@ def test_two_ranks_ulysses_at_14b_block_dims():
     assert r.stdout.count("fsdp_rel=0.000e+00") == 2, r.stdout[-2000:]
 
 
-@pytest.mark.parametrize("gpus,plan", [(2, "cfg2xsp1"), (4, "cfg2xsp2")])
-def test_bench_multi_rank_control_flow_rehearsal(gpus, plan):
+@pytest.mark.parametrize("gpus,plan,extra", [(2, "cfg2xsp1", []), (4, "cfg2xsp2", []),
+                                             (2, "cfg1xsp2", ["--no-cfg-parallel", "--dit-fsdp", "--quant-config", "w4a8_mixed.yaml"])])
+def test_bench_multi_rank_control_flow_rehearsal(gpus, plan, extra):
     """bench.py --gpus N end to end (cfg-A frame count so that it takes seconds): rendezvous, parallel plan, calibration on
     every rank, timed step with the cfg all-gather, max-over-ranks timing, one JSON line from rank 0."""
     import json
@@ -48,7 +49,7 @@ def test_bench_multi_rank_control_flow_rehearsal(gpus, plan):
     root = os.path.dirname(HERE)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "0",
-           "--frames", "9", "--no-cpu-baseline", "--no-quality"]
+           "--frames", "9", "--no-cpu-baseline", "--no-quality", *extra]
     env = dict(os.environ, OMP_NUM_THREADS="4", WANQ_BENCH_REHEARSE_ON_ONE_GPU="1")
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, f"bench rehearsal failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
@@ -57,3 +58,5 @@ def test_bench_multi_rank_control_flow_rehearsal(gpus, plan):
     out = json.loads(lines[0])
     assert out["n_gpus"] == gpus and out["config"]["parallelism"] == plan and out["value"] > 0 and out["config"]["rccl_ranks"] == gpus
     assert out["roofline"]["frac"] > 0 and "REHEARSAL" in out["data"]
+    if extra:  # the flags of BASELINE config 5 (pure Ulysses + sharded packed-W4 / W8 weights), on the 1.3B model
+        assert out["config"]["dit_fsdp"]["ranks"] == gpus and "W4A8" in out["config"]["workload"] and "W4A8-mixed" in out["metric"]
