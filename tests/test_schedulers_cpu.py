@@ -1,5 +1,6 @@
 """Host-side samplers (CPU): schedule values per SURVEY Appendix C, Euler consistency, exactness on linear fields."""
 import numpy as np
+import pytest
 import torch
 
 from wan.utils.fm_solvers import FlowMatchScheduler
@@ -136,3 +137,48 @@ def test_fused_step_equals_scheduler_for_all_solvers():
             assert f.n_launch == 9
     finally:
         fs.lincomb = saved
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Pinned: the reference's own scheduler files driven on seeded model outputs (tests/golden/make_golden_schedulers.py)
+@pytest.mark.parametrize("n", [3, 10, 50])
+def test_unipc_vs_reference_golden(n):
+    """FlowUniPCMultistepScheduler (bh2, order 2, lower_order_final) == the reference's, step by step: timesteps exact, sigmas and
+    every latent of the trajectory to fp32 rounding."""
+    import os
+
+    import numpy as np
+    from wan.utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"sched_unipc_{n}.npz"))
+    s = FlowUniPCMultistepScheduler(1000, shift=1.0)
+    s.set_timesteps(n, device="cpu", shift=5.0)
+    assert np.array_equal(s.timesteps.numpy(), g["timesteps"])
+    np.testing.assert_allclose(np.asarray(s.sigmas, dtype=np.float64), g["sigmas"].astype(np.float64), rtol=2e-7, atol=1e-9)
+    x = torch.from_numpy(g["x"][0])
+    for i, t in enumerate(s.timesteps):
+        x = s.step(torch.from_numpy(g["model_out"][i]), t, x)
+        ref = g["x"][i + 1]
+        assert float(np.abs(x.numpy() - ref).max()) <= 2e-5 * float(np.abs(ref).max()), (n, i)
+
+
+@pytest.mark.parametrize("n", [3, 10, 50])
+def test_dpmpp_vs_reference_golden(n):
+    """FlowDPMSolverMultistepScheduler (dpmsolver++, midpoint, order 2) == the reference's on the `--sample_solver dpm++` schedule
+    (sigmas from get_sampling_sigmas, text2video.py:223-232)."""
+    import os
+
+    import numpy as np
+    from wan.utils.fm_solvers import FlowDPMSolverMultistepScheduler, get_sampling_sigmas
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"sched_dpmpp_{n}.npz"))
+    np.testing.assert_allclose(get_sampling_sigmas(n, 5.0), g["sampling_sigmas"], rtol=1e-15)
+    s = FlowDPMSolverMultistepScheduler(1000)
+    s.set_timesteps(n, device="cpu", shift=5.0)
+    assert np.array_equal(s.timesteps.numpy(), g["timesteps"])
+    np.testing.assert_allclose(np.asarray(s.sigmas, dtype=np.float64), g["sigmas"].astype(np.float64), rtol=2e-7, atol=1e-9)
+    x = torch.from_numpy(g["x"][0])
+    for i, t in enumerate(s.timesteps):
+        x = s.step(torch.from_numpy(g["model_out"][i]), t, x)
+        ref = g["x"][i + 1]
+        assert float(np.abs(x.numpy() - ref).max()) <= 2e-5 * float(np.abs(ref).max()), (n, i)

@@ -50,8 +50,9 @@ class FlowDPMSolverMultistepScheduler:
     "midpoint", lower_order_final, final_sigmas_type "zero").  Host restatement like the UniPC one: float64 scalars, the update
     is linear in latent-sized tensors.  Restated lines: convert_model_output (flow_prediction) :341-395, first-order update
     :415-484, second-order multistep update :486-594, step control flow :706-800; sigma schedule :22-26 + :226-290.
-    Parity status: UNPINNED (needs diffusers; no fixture in the reference); tests/test_schedulers_cpu.py checks the first step
-    against the Euler step, exactness on a constant velocity field and second-order convergence."""
+    Parity: PINNED -- tests/golden/sched_dpmpp_{3,10,50}.npz hold trajectories produced by the reference's own fm_solvers.py
+    (tests/golden/make_golden_schedulers.py loads the file stand-alone with a stand-in for the diffusers configuration mixins);
+    tests/test_schedulers_cpu.py compares timesteps exactly and every latent to 2e-5, besides the closed-form properties."""
 
     def __init__(self, num_train_timesteps=1000, solver_order=2, shift=1.0, lower_order_final=True):
         assert solver_order in (1, 2), "orders 1 and 2 are implemented (the reference's default is 2)"

@@ -4,9 +4,11 @@ lower-order final step) for flow-matching models -- the default `--sample_solver
 
 Host-side restatement: the step coefficients are Python floats (float64), the update is a handful of elementwise torch
 ops on the 2 MB latent.  Interface: set_timesteps(n, device, shift) / timesteps / step(model_output, timestep, sample).
-Parity status: UNPINNED (the reference file imports diffusers, which is absent here, and the reference holds no fixture for
-it).  What is tested instead (tests/test_schedulers_cpu.py): an order-1 step equals the flow-matching Euler step; a
-constant velocity field is integrated exactly; the schedule equals FlowMatchScheduler's."""
+Parity: PINNED -- tests/golden/sched_unipc_{3,10,50}.npz hold trajectories produced by the reference's own file
+(tests/golden/make_golden_schedulers.py loads it stand-alone with a stand-in for the diffusers configuration mixins it inherits;
+all arithmetic is the reference's); tests/test_schedulers_cpu.py compares timesteps exactly and every latent of the trajectory to
+2e-5.  Also tested: an order-1 step equals the flow-matching Euler step; a constant velocity field is integrated exactly; the
+schedule equals FlowMatchScheduler's."""
 import math
 
 import numpy as np
