@@ -21,6 +21,7 @@ Which reference entry point produced which file:
   a5_hadamard_*.npz   matmul_hadU / random_hadamard_matrix  Q/quarot/quarot_utils.py:158-192
   a4_viditq.npz       ViDiTQuantizedLinear                  Q/viditq/viditq_quant_layer.py:8-73
   a8_calib.npz        SaveActivationHook default branch     W/get_calib_data_wanx.py:262-267,443-449 ; W/ptq_wanx.py:334-344
+  a16_qkv_attn.npz    DynamicQuantizer with the q / k / v reshapes of quantized attention   W/models/quant_opensora.py:431-440
   a12_intweight.npz   quantize_and_save_weight_ equation    W/wan/quant_wanx_cuda.py:39-53 (4-line equation applied to a1's delta/zp)
   kbench_*.npz        closed-form ground truths of K/bench/bench_gemm.py:27-29,
                       bench_quant_kernel.py:8-11,24-26, bench_layer_norm_kernel.py:15-16,34-36,47-49
@@ -318,7 +319,30 @@ def gen_kbench():
          q_scale=sc.view(-1), q=qy.to(torch.int32), q_sum=sm)
 
 
+def gen_a16():
+    """q / k / v of the reference's quantized attention: its DynamicQuantizer applied with the exact reshapes of
+    examples/Wan2.1/models/quant_opensora.py:431-440 -- q and k per (token, head) over head_dim, v per (head, channel) over all
+    tokens -- on [B, heads, tokens, head_dim] tensors (the layout of that file)."""
+    g = torch.Generator().manual_seed(16)
+    BS, H, N, D = 1, 3, 37, 128
+    q = torch.randn(BS, H, N, D, generator=g) * torch.exp(0.5 * torch.randn(D, generator=g))
+    k = torch.randn(BS, H, N, D, generator=g) * 2.0
+    v = torch.randn(BS, H, N, D, generator=g) * torch.exp(torch.randn(H, 1, D, generator=g))
+    v[:, 1, :, 7] = 0  # an all-zero (head, channel): the eps rule
+    out = {}
+    for bits in (8, 4):
+        cfg = OmegaConf.create({"n_bits": bits, "sym": True})
+        qq, kq, vq = DynamicQuantizer(cfg), DynamicQuantizer(cfg), DynamicQuantizer(cfg)
+        for z in (qq, kq, vq):
+            z.module_name = "golden"  # only read by the eps branch's log line (the owning layer sets it in the reference)
+        out[f"q{bits}"] = qq(q.reshape([-1, D])).reshape([BS, H, N, D])                      # :432
+        out[f"k{bits}"] = kq(k.reshape([-1, D])).reshape([BS, H, N, D])                      # :436
+        out[f"v{bits}"] = vq(v.permute([0, 1, 3, 2]).reshape([-1, N])).reshape([BS, H, D, N]).permute([0, 1, 3, 2])  # :438-440
+    save("a16_qkv_attn", q=q, k=k, v=v, **out)
+
+
 if __name__ == "__main__":
+    gen_a16()
     gen_a2()
     gen_a1()
     gen_a3()

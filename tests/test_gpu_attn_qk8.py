@@ -207,3 +207,34 @@ def test_kernel_mode_block_with_quantized_v_vs_oracle(tmp_path):
     m2.set_init_done()
     with pytest.raises(NotImplementedError, match="attention map"):
         m2.hardware_forward_refactor()
+
+
+@pytest.mark.parametrize("bits", [8, 4])
+def test_v_fake_quant_kernel_vs_reference_golden(golden, bits):
+    """wanq_col_absmax + wanq_fake_quant_cols on the token-major [tokens, heads*128] tensor == the reference's v quantiser
+    (fixture a16_qkv_attn, made by its DynamicQuantizer with the reshape of quant_opensora.py:438-440), bit for bit."""
+    import viditq_extension.fused as fused
+
+    g = golden("a16_qkv_attn")
+    v = torch.from_numpy(g["v"])[0].permute(1, 0, 2).reshape(g["v"].shape[2], -1).contiguous()      # [N, H*D]
+    ref = torch.from_numpy(g[f"v{bits}"])[0].permute(1, 0, 2).reshape(v.shape)
+    out, _ = fused.fake_quant_cols_(v.to(DEV).clone(), bits)
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_qk_int8_codes_vs_reference_golden(golden):
+    """The per-(token, head) int8 form the int8 Q.K^T attention consumes (wanq_rmsnorm_rope_q8, here with an identity rotation and
+    no norm so that only its quantiser acts) dequantises to exactly what the reference's q / k quantiser returns (a16_qkv_attn)."""
+    from wan import ops
+
+    g = golden("a16_qkv_attn")
+    n_tok, H, D = g["q"].shape[2], g["q"].shape[1], g["q"].shape[3]
+    ident = torch.zeros(n_tok, D // 2, 2, device=DEV)
+    ident[..., 0] = 1.0  # cos = 1, sin = 0
+    for name in ("q", "k"):
+        x = torch.from_numpy(g[name])[0].permute(1, 0, 2).reshape(n_tok, H * D).contiguous().to(DEV)
+        ref = torch.from_numpy(g[f"{name}8"])[0].permute(1, 0, 2).reshape(n_tok, H * D)
+        q8 = ops.rmsnorm_rope_q8(x, None, ident, D, for_keys=(name == "k"))
+        delta = q8.scales[0, :, :n_tok].t().contiguous()  # [tokens, heads]
+        deq = q8.codes.float().view(n_tok, H, D) * delta.unsqueeze(-1)
+        assert torch.equal(deq.view(n_tok, H * D).cpu(), ref)

@@ -202,3 +202,20 @@ def test_a4_viditq_layer_1536(golden):
     # the fast transform used by the product equals the dense product with R
     np.testing.assert_allclose(qr.matmul_hadU((g["x"].reshape(-1, 1536) * g["channel_mask"]).astype(np.float64) * g["signs"]),
                                g["x_rot"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("bits", [8, 4])
+def test_a16_attention_qkv_quantisers_vs_reference(golden, bits):
+    """oracle/wan_ref.py qk_fake_quant / v_fake_quant == the reference's DynamicQuantizer with the reshapes of its quantized
+    attention (quant_opensora.py:431-440): q, k per (token, head) over head_dim; v per (head, channel) over all tokens."""
+    import torch
+
+    from oracle import wan_ref as wr
+
+    g = golden("a16_qkv_attn")
+    for name in ("q", "k"):
+        x = torch.from_numpy(g[name])[0].permute(1, 0, 2).contiguous()  # [B, H, N, D] -> [N, H, D], the oracle's layout
+        ref = torch.from_numpy(g[f"{name}{bits}"])[0].permute(1, 0, 2)
+        assert torch.equal(wr.qk_fake_quant(x, bits), ref)
+    v = torch.from_numpy(g["v"])[0].permute(1, 0, 2).contiguous()
+    assert torch.equal(wr.v_fake_quant(v, bits), torch.from_numpy(g[f"v{bits}"])[0].permute(1, 0, 2))
