@@ -21,6 +21,7 @@ Which reference entry point produced which file:
   a5_hadamard_*.npz   matmul_hadU / random_hadamard_matrix  Q/quarot/quarot_utils.py:158-192
   a4_viditq.npz       ViDiTQuantizedLinear                  Q/viditq/viditq_quant_layer.py:8-73
   a8_calib.npz        SaveActivationHook default branch     W/get_calib_data_wanx.py:262-267,443-449 ; W/ptq_wanx.py:334-344
+  a6_surgery.npz      quant_layer_refactor_ / save_quant_param_dict_ / bitwidth_refactor_ on a Wan-named toy tree   Q/base/quant_model.py:15-172
   a16_qkv_attn.npz    DynamicQuantizer with the q / k / v reshapes of quantized attention   W/models/quant_opensora.py:431-440
   a12_intweight.npz   quantize_and_save_weight_ equation    W/wan/quant_wanx_cuda.py:39-53 (4-line equation applied to a1's delta/zp)
   kbench_*.npz        closed-form ground truths of K/bench/bench_gemm.py:27-29,
@@ -341,7 +342,89 @@ def gen_a16():
     save("a16_qkv_attn", q=q, k=k, v=v, **out)
 
 
+def gen_a6_surgery():
+    """Model surgery and the quant_param_dict, by the reference's own functions driven with QuantWanModel's keyword arguments
+    (W/wan/quant_wanx.py:85-133 -> Q/base/quant_model.py:15-172) on a toy tree that carries Wan's module names.  Stored: which
+    Linear became which class under the shipped config.yaml regexes, the key / shape map of save_quant_param_dict after the ViDiT
+    initialisation, and -- under a mixed-precision config -- every layer's weight bit-width and quant_mode."""
+    import json
+
+    import torch.nn as nn
+    from qdiff.base.base_quantizer import BaseQuantizer
+    from qdiff.base.quant_model import bitwidth_refactor_, quant_layer_refactor_, save_quant_param_dict_, set_init_done_
+    from qdiff.utils import apply_func_to_submodules
+
+    def tree():
+        torch.manual_seed(6)
+
+        class Attn(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.q, self.k, self.v, self.o = (nn.Linear(256, 256) for _ in range(4))
+
+        class Block(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.self_attn, self.cross_attn = Attn(), Attn()
+                self.ffn = nn.Sequential(nn.Linear(256, 512), nn.GELU(approximate="tanh"), nn.Linear(512, 256))
+
+        class Head(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.head = nn.Linear(256, 64)
+
+        class Toy(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.text_embedding = nn.Sequential(nn.Linear(64, 256), nn.GELU(approximate="tanh"), nn.Linear(256, 256))
+                self.time_embedding = nn.Sequential(nn.Linear(64, 256), nn.SiLU(), nn.Linear(256, 256))
+                self.time_projection = nn.Sequential(nn.SiLU(), nn.Linear(256, 1536))
+                self.blocks = nn.ModuleList([Block(), Block()])
+                self.head = Head()
+                self.quant_param_dict = {}
+
+        return Toy()
+
+    def refactor(model, cfg):
+        apply_func_to_submodules(model, class_type=nn.Linear, function=quant_layer_refactor_, name=None, parent_module=None,
+                                 quant_config=cfg, full_name=None, remain_fp_regex=cfg.remain_fp_regex)
+
+    def classes(model):
+        return {n: type(m).__name__ for n, m in model.named_modules() if isinstance(m, nn.Linear) or hasattr(m, "w_quantizer")}
+
+    out = {}
+    # (1) the shipped Wan config: W8A8, ViDiT on every quantized layer, FP everywhere but self_attn q / k / v
+    import yaml
+    with open("/root/reference/ViDiT-Q/examples/Wan2.1/quant_configs/config.yaml") as fh:
+        wan_cfg = OmegaConf.create(yaml.safe_load(fh))
+    m = tree()
+    refactor(m, wan_cfg)
+    out["wan_config_classes"] = classes(m)
+    g = torch.Generator().manual_seed(7)
+    for n, mod in m.named_modules():
+        if type(mod).__name__ == "ViDiTQuantizedLinear":  # what ptq_wanx.py:334-344 does per layer, on the CPU
+            mod.get_channel_mask(torch.rand(mod.in_features, generator=g) + 0.5)
+            mod.rotation_matrix = hadamard_from_signs(torch.randint(0, 2, (mod.in_features,), generator=g).double() * 2 - 1)
+            mod.update_quantized_weight_rotated_and_scaled()
+    apply_func_to_submodules(m, class_type=BaseQuantizer, function=save_quant_param_dict_, full_name=None, parent_module=None, model=m)
+    out["wan_config_param_dict"] = {k: {kk: (None if vv is None else list(vv.shape)) for kk, vv in v.items()} for k, v in m.quant_param_dict.items()}
+    # (2) mixed precision: weight bit-width list, regex lists with index 0 = FP16
+    mp_cfg = OmegaConf.create({"remain_fp_regex": r"text_embedding|time_embedding|time_projection|head\.head",
+                               "weight": {"n_bits": [4, 8], "i_bitwidth": 1, "sym": False}, "act": {"n_bits": 8, "sym": True},
+                               "mixed_precision": {"weight": {"layer_name_regex": [r"cross_attn\.o", "ffn", ""]},
+                                                   "act": {"layer_name_regex": ["", ""]}}})
+    m2 = tree()
+    refactor(m2, mp_cfg)
+    from qdiff.base.quant_layer import QuantizedLinear as QL
+    apply_func_to_submodules(m2, class_type=QL, function=bitwidth_refactor_, name=None, parent_module=None, quant_config=mp_cfg, full_name=None)
+    out["mixed_classes"] = classes(m2)
+    out["mixed_bits"] = {n: {"w_bits": int(mod.w_quantizer.n_bits), "quant_mode": bool(mod.quant_mode)} for n, mod in m2.named_modules()
+                         if hasattr(mod, "w_quantizer")}
+    save("a6_surgery", json=np.array(json.dumps(out, sort_keys=True)))
+
+
 if __name__ == "__main__":
+    gen_a6_surgery()
     gen_a16()
     gen_a2()
     gen_a1()

@@ -362,3 +362,87 @@ def test_refresh_keeps_rotated_weights_consistent_under_mixed_precision():
     ref = qr.vidit_linear(x.numpy()[None], w_final, lin.bias.detach().cpu().numpy(), mask, R)
     ref = ref[0] if ref.ndim == 3 else ref
     assert np.abs(y.cpu().numpy() - ref).max() < 2e-2 * np.abs(ref).max()
+
+
+def test_surgery_and_param_dict_vs_reference_golden(golden):
+    """quant_layer_refactor_ / save_quant_param_dict_ / bitwidth_refactor_ on a toy tree with Wan's module names, driven with the
+    keyword arguments QuantWanModel uses, against what the reference's own functions did on the same tree (fixture a6_surgery):
+    which Linear becomes which class under the reference's shipped config.yaml, the quant_param_dict's keys and shapes (our extra
+    `rotation_signs` entry aside), and per-layer bit-width / quant_mode under a mixed-precision config."""
+    import json
+
+    import torch.nn as nn
+    import yaml
+
+    from qdiff import config as qcfg
+    from qdiff.base.base_quantizer import BaseQuantizer
+    from qdiff.base.quant_layer import QuantizedLinear
+    from qdiff.base.quant_model import bitwidth_refactor_, quant_layer_refactor_, save_quant_param_dict_
+    from qdiff.utils import apply_func_to_submodules
+
+    ref = json.loads(str(golden("a6_surgery")["json"]))
+
+    class Attn(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q, self.k, self.v, self.o = (nn.Linear(256, 256) for _ in range(4))
+
+    class Block(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.self_attn, self.cross_attn = Attn(), Attn()
+            self.ffn = nn.Sequential(nn.Linear(256, 512), nn.GELU(approximate="tanh"), nn.Linear(512, 256))
+
+    class Head(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.head = nn.Linear(256, 64)
+
+    class Toy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.text_embedding = nn.Sequential(nn.Linear(64, 256), nn.GELU(approximate="tanh"), nn.Linear(256, 256))
+            self.time_embedding = nn.Sequential(nn.Linear(64, 256), nn.SiLU(), nn.Linear(256, 256))
+            self.time_projection = nn.Sequential(nn.SiLU(), nn.Linear(256, 1536))
+            self.blocks = nn.ModuleList([Block(), Block()])
+            self.head = Head()
+            self.quant_param_dict = {}
+
+    def refactor(model, c):
+        apply_func_to_submodules(model, class_type=nn.Linear, function=quant_layer_refactor_, name=None, parent_module=None,
+                                 quant_config=c, full_name=None, remain_fp_regex=c.remain_fp_regex)
+
+    def classes(model):
+        return {n: type(m).__name__ for n, m in model.named_modules() if isinstance(m, nn.Linear) or hasattr(m, "w_quantizer")}
+
+    # (1) the reference's shipped Wan config, verbatim
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "..", "wan2.1-quantization_amd", "quant_configs", "config.yaml")) as fh:
+        wan_cfg = qcfg.create(yaml.safe_load(fh))
+    torch.manual_seed(6)
+    m = Toy().to(DEV)
+    refactor(m, wan_cfg)
+    mine = classes(m)
+    # the reference keeps the wrapped nn.Linear as `.fp_module` of every quantized layer: those names appear in both maps
+    assert mine == ref["wan_config_classes"]
+    g = torch.Generator().manual_seed(7)
+    for n, mod in m.named_modules():
+        if type(mod).__name__ == "ViDiTQuantizedLinear":
+            mod.get_channel_mask((torch.rand(mod.in_features, generator=g) + 0.5).to(DEV))
+            mod.rotation_signs = torch.randint(0, 2, (mod.in_features,), generator=g).double() * 2 - 1
+            mod.update_quantized_weight_rotated_and_scaled()
+    apply_func_to_submodules(m, class_type=BaseQuantizer, function=save_quant_param_dict_, full_name=None, parent_module=None, model=m)
+    shapes = {k: {kk: (None if vv is None else list(vv.shape)) for kk, vv in v.items() if kk != "rotation_signs"} for k, v in m.quant_param_dict.items()}
+    assert shapes == ref["wan_config_param_dict"]
+    assert all("rotation_signs" in v for v in m.quant_param_dict.values())  # ours in addition: the rotation is rebuilt from it exactly
+    # (2) mixed precision
+    mp = qcfg.create({"remain_fp_regex": r"text_embedding|time_embedding|time_projection|head\.head",
+                      "weight": {"n_bits": [4, 8], "i_bitwidth": 1, "sym": False}, "act": {"n_bits": 8, "sym": True},
+                      "mixed_precision": {"weight": {"layer_name_regex": [r"cross_attn\.o", "ffn", ""]}, "act": {"layer_name_regex": ["", ""]}}})
+    torch.manual_seed(6)
+    m2 = Toy().to(DEV)
+    refactor(m2, mp)
+    apply_func_to_submodules(m2, class_type=QuantizedLinear, function=bitwidth_refactor_, name=None, parent_module=None, quant_config=mp, full_name=None)
+    assert classes(m2) == ref["mixed_classes"]
+    bits = {n: {"w_bits": int(mod.w_quantizer.n_bits), "quant_mode": bool(mod.quant_mode)} for n, mod in m2.named_modules() if hasattr(mod, "w_quantizer")}
+    assert bits == ref["mixed_bits"]
