@@ -20,6 +20,7 @@ Which reference entry point produced which file:
   a3_qlinear.npz      QuantizedLinear.forward               Q/base/quant_layer.py:14-74
   a5_hadamard_*.npz   matmul_hadU / random_hadamard_matrix  Q/quarot/quarot_utils.py:158-192
   a4_viditq.npz       ViDiTQuantizedLinear                  Q/viditq/viditq_quant_layer.py:8-73
+  a4_smoothquant_1536.npz / a4_quarot_1536.npz   SQQuantizedLinear / QuarotQuantizedLinear   Q/smooth_quant/sq_quant_layer.py, Q/quarot/quarot_quant_layer.py
   a8_calib.npz        SaveActivationHook default branch     W/get_calib_data_wanx.py:262-267,443-449 ; W/ptq_wanx.py:334-344
   a6_surgery.npz      quant_layer_refactor_ / save_quant_param_dict_ / bitwidth_refactor_ on a Wan-named toy tree   Q/base/quant_model.py:15-172
   a16_qkv_attn.npz    DynamicQuantizer with the q / k / v reshapes of quantized attention   W/models/quant_opensora.py:431-440
@@ -342,6 +343,57 @@ def gen_a16():
     save("a16_qkv_attn", q=q, k=k, v=v, **out)
 
 
+def gen_a4_sq_quarot():
+    """The other two transform layers of the reference at in_features 1536 (one Wan model dimension): SmoothQuant
+    (SQQuantizedLinear, Q/smooth_quant/sq_quant_layer.py:6-68: channel mask only) and QuaRot (QuarotQuantizedLinear,
+    Q/quarot/quarot_quant_layer.py:7-69: rotation only).  QuaRot's weight update moves the weight `.to("cuda")` (:38): on this
+    CPU-only container that one call is redirected to the CPU for the duration of the update."""
+    from qdiff.quarot.quarot_quant_layer import QuarotQuantizedLinear
+    from qdiff.smooth_quant.sq_quant_layer import SQQuantizedLinear
+
+    g = torch.Generator().manual_seed(44)
+    n, out = 1536, 24
+    base = {"weight": {"n_bits": 8, "sym": False}, "act": {"n_bits": 8, "sym": True}}
+
+    def lin_():
+        lin = torch.nn.Linear(n, out)
+        lin.weight.data = torch.randn(out, n, generator=g) * 0.05
+        lin.weight.data[:, 11] *= 8.0
+        lin.bias.data = torch.randn(out, generator=g) * 0.1
+        return lin
+
+    # SmoothQuant
+    lin = lin_()
+    sq = SQQuantizedLinear(n, out, True, "cpu", OmegaConf.create(dict(base, smooth_quant={"alpha": 0.5, "layer_name_regex": ""})), lin)
+    sq.a_quantizer.module_name = "golden"
+    act_mask = outlier_acts(g, 64, n).abs().max(dim=0)[0]
+    act_mask = torch.where(act_mask < 1e-3, torch.tensor(1e-3), act_mask)
+    sq.get_channel_mask(act_mask)
+    sq.update_quantized_weight_scaled()
+    x = outlier_acts(g, 9, n).reshape(1, 9, n)
+    save("a4_smoothquant_1536", x=x, w=lin.weight.data, b=lin.bias.data, act_mask=act_mask, channel_mask=sq.channel_mask,
+         w_final=sq.weight.data, w_delta=sq.w_quantizer.delta.reshape(-1), w_zp=sq.w_quantizer.zero_point.reshape(-1), y=sq(x))
+    # QuaRot
+    lin = lin_()
+    qr_ = QuarotQuantizedLinear(n, out, True, "cpu", OmegaConf.create(dict(base, quarot={"layer_name_regex": ""})), lin)
+    qr_.a_quantizer.module_name = "golden"
+    s = (torch.randint(0, 2, (n,), generator=g) * 2 - 1).to(torch.float64)
+    qr_.rotation_matrix = hadamard_from_signs(s)
+    real_to = torch.Tensor.to
+    torch.Tensor.to = lambda self, *a, **k: real_to(self, *[("cpu" if (isinstance(v, str) and v == "cuda") else v) for v in a], **k)
+    try:
+        qr_.update_quantized_weight_rotated()
+    finally:
+        torch.Tensor.to = real_to
+    x = outlier_acts(g, 9, n).reshape(1, 9, n)
+    y = qr_(x)
+    xr = torch.matmul(x.double(), qr_.rotation_matrix).to(x.dtype).reshape(9, n)
+    a_q = DynamicQuantizer(OmegaConf.create(base["act"]))
+    a_q.module_name = "golden"
+    save("a4_quarot_1536", x=x, w=lin.weight.data, b=lin.bias.data, signs=s, w_final=qr_.weight.data,
+         w_delta=qr_.w_quantizer.delta.reshape(-1), w_zp=qr_.w_quantizer.zero_point.reshape(-1), y=y, x_q=a_q.quantize(xr), x_delta=a_q.delta.reshape(-1))
+
+
 def gen_a6_surgery():
     """Model surgery and the quant_param_dict, by the reference's own functions driven with QuantWanModel's keyword arguments
     (W/wan/quant_wanx.py:85-133 -> Q/base/quant_model.py:15-172) on a toy tree that carries Wan's module names.  Stored: which
@@ -424,6 +476,7 @@ def gen_a6_surgery():
 
 
 if __name__ == "__main__":
+    gen_a4_sq_quarot()
     gen_a6_surgery()
     gen_a16()
     gen_a2()

@@ -446,3 +446,48 @@ def test_surgery_and_param_dict_vs_reference_golden(golden):
     assert classes(m2) == ref["mixed_classes"]
     bits = {n: {"w_bits": int(mod.w_quantizer.n_bits), "quant_mode": bool(mod.quant_mode)} for n, mod in m2.named_modules() if hasattr(mod, "w_quantizer")}
     assert bits == ref["mixed_bits"]
+
+
+def test_smoothquant_linear_vs_reference_golden(golden):
+    """SQQuantizedLinear (channel mask only) at in_features 1536 against the reference's own module (fixture a4_smoothquant_1536):
+    mask, scaled + quantised weight bit for bit, forward output."""
+    from qdiff.base.quant_layer import SQQuantizedLinear
+
+    g = golden("a4_smoothquant_1536")
+    n, out = 1536, 24
+    lin = torch.nn.Linear(n, out).to(DEV)
+    lin.weight.data, lin.bias.data = t(g["w"]), t(g["b"])
+    sq = SQQuantizedLinear(n, out, True, DEV, cfg(smooth_quant={"alpha": 0.5, "layer_name_regex": ""}), lin)
+    sq.get_channel_mask(t(g["act_mask"]))
+    np.testing.assert_allclose(sq.channel_mask.cpu().numpy(), g["channel_mask"], rtol=3e-7)  # powf ulp
+    sq.channel_mask = t(g["channel_mask"])
+    sq.update_quantized_weight_scaled()
+    assert np.array_equal(sq.w_quantizer.delta.reshape(-1).cpu().numpy(), g["w_delta"])
+    assert np.array_equal(sq.w_quantizer.zero_point.reshape(-1).cpu().numpy(), g["w_zp"])
+    assert np.array_equal(sq.weight.data.cpu().numpy(), g["w_final"])
+    y = sq(t(g["x"]))
+    assert np.abs(y.cpu().numpy() - g["y"]).max() < 2e-5 * np.abs(g["y"]).max() + 2e-5  # int8 GEMM vs fp32 linear on the same codes
+
+
+def test_quarot_linear_vs_reference_golden(golden):
+    """QuarotQuantizedLinear (rotation only) at in_features 1536 against the reference's own module (fixture a4_quarot_1536):
+    rotated + quantised weight (fp32 fast transform vs the reference's fp64 product: a code moves only at a .5 boundary),
+    activation codes, forward output."""
+    from qdiff.base.quant_layer import QuarotQuantizedLinear
+
+    g = golden("a4_quarot_1536")
+    n, out = 1536, 24
+    lin = torch.nn.Linear(n, out).to(DEV)
+    lin.weight.data, lin.bias.data = t(g["w"]), t(g["b"])
+    ql = QuarotQuantizedLinear(n, out, True, DEV, cfg(quarot={"layer_name_regex": ""}), lin)
+    ql.rotation_signs = torch.from_numpy(g["signs"])
+    ql.update_quantized_weight_rotated()
+    np.testing.assert_allclose(ql.w_quantizer.delta.reshape(-1).cpu().numpy(), g["w_delta"], rtol=2e-6)
+    dw = np.abs(ql.weight.data.cpu().numpy() - g["w_final"]) / g["w_delta"].reshape(-1, 1)
+    assert dw.max() <= 1.0 + 1e-3 and (dw > 0.5).mean() < 2e-3
+    q, scale, _ = ql.a_quantizer.quantize_int8(t(g["x"]).reshape(-1, n), *ql._act_transform())
+    np.testing.assert_allclose(scale.cpu().numpy(), g["x_delta"], rtol=2e-6)
+    d = np.abs(q.cpu().numpy().astype(np.int32) - g["x_q"].astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3
+    y = ql(t(g["x"]))
+    assert np.abs(y.cpu().numpy() - g["y"]).max() < 5e-3 * np.abs(g["y"]).max() + 1e-3
