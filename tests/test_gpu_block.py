@@ -334,3 +334,58 @@ def test_config5_w4a8_mixed_block_14b_shapes_and_checkpoint_roundtrip(tmp_path):
         bad = {k: v for k, v in sdw.items() if k != "blocks.0.cross_attn.o.scale_weight"}
         torch.save(bad, path)
         model2.hardware_forward_refactor(path)
+
+
+def test_reference_format_checkpoint_layout_and_reload(tmp_path):
+    """quantize_and_save_weight(reference_format=True) on a model quantised with the reference's shipped config.yaml (W8A8 on
+    self_attn q / k / v, the rest FP): the state dict has the key set / dtypes the reference's kernel-mode loader reads (SURVEY
+    Appendix C: `blocks.i.self_attn.{q,k,v}.{weight int8, scale_weight f16, zp_weight f16 (integer valued), bias f16}`, FP
+    `o` / `cross_attn` / `ffn` as fp16 parameters, `norm1/2.weight` = ones, no fp_module / fp_weight / quantizer entries), and
+    hardware_forward_refactor(path) loads it back: the kernel-mode output moves only by the fp16 rounding of the scales."""
+    import os
+
+    import yaml
+
+    from qdiff import config as qcfg
+    from wan.configs import seq_len_for
+    from wan.modules.model import WanModel
+    from wan.quant_wanx import QuantWanModel
+
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "wan2.1-quantization_amd", "quant_configs", "config.yaml")) as fh:
+        raw = yaml.safe_load(fh)
+    raw["viditq"] = None  # the reference's kernel path has no activation transform: export the plain W8A8 form of the same layers
+    quant_config = qcfg.create({k: v for k, v in raw.items() if v is not None})
+    torch.manual_seed(0)
+    with torch.device(DEV):
+        fp = WanModel(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64, freq_dim=64).eval()
+    g = torch.Generator(device=DEV).manual_seed(2)
+    torch.nn.init.xavier_uniform_(fp.head.head.weight, generator=g)
+    model = QuantWanModel.from_float(fp, quant_config)
+    model.quant_layer_refactor()
+    model.set_init_done()
+    path = str(tmp_path / "int_weight.pt")
+    sd = model.quantize_and_save_weight(path, reference_format=True)
+    for l in "qkv":
+        base = f"blocks.1.self_attn.{l}"
+        assert sd[base + ".weight"].dtype == torch.int8 and tuple(sd[base + ".weight"].shape) == (256, 256)
+        assert sd[base + ".scale_weight"].dtype == torch.float16 and sd[base + ".zp_weight"].dtype == torch.float16 and sd[base + ".bias"].dtype == torch.float16
+        assert torch.equal(sd[base + ".zp_weight"], sd[base + ".zp_weight"].round())  # integer valued: the loader copies it into int16
+        assert base + ".act_premul" not in sd
+    assert sd["blocks.0.self_attn.o.weight"].dtype == torch.float16 and sd["blocks.0.ffn.0.weight"].dtype == torch.float16
+    assert torch.equal(sd["blocks.0.norm1.weight"], torch.ones(256, dtype=torch.float16)) and "blocks.1.norm2.weight" in sd
+    assert not any(("fp_module" in k or "fp_weight" in k or "quantizer" in k) for k in sd)
+    # reload into kernel mode
+    shape = (16, 2, 8, 6)
+    gl = torch.Generator(device=DEV).manual_seed(3)
+    latent = torch.randn(shape, generator=gl, device=DEV)
+    ctx = torch.randn(16, 64, generator=gl, device=DEV) * 0.1
+    t = torch.tensor([500], device=DEV)
+    model.hardware_forward_refactor()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        ref = model([latent], t, [ctx], seq_len_for(shape))[0].float()
+    model.hardware_forward_refactor(path)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        out = model([latent], t, [ctx], seq_len_for(shape))[0].float()
+    err = rel_err(out.cpu(), ref.cpu())
+    print(f"kernel mode from the reference-format checkpoint vs from the in-memory layers: {err:.2e}")
+    assert 0 < err < 5e-3  # fp16 scales / biases: not bit-equal, and not far
