@@ -248,6 +248,10 @@ def main():
     model.hardware_forward_refactor()
     n_quant = sum(1 for m in model.modules() if isinstance(m, QuantizedLinear))
     n_w4 = sum(1 for b in model.hip_blocks for m in b.modules() if getattr(m, "w_bits", 8) == 4)
+    hb0 = model.hip_blocks[0]
+    attn_desc = "bf16" if not (hb0.attn_qk8 or hb0.cross_attn_qk8 or hb0.attn_v_bits or hb0.cross_attn_v_bits) else ", ".join(
+        [f"{nm}: " + " + ".join((["int8 Q.K^T (q, k per (token, head))"] if qk else []) + ([f"v {vb}-bit per (head, channel)"] if vb else []))
+         for nm, qk, vb in (("self", hb0.attn_qk8, hb0.attn_v_bits), ("cross", hb0.cross_attn_qk8, hb0.cross_attn_v_bits)) if qk or vb]) + "; P.V bf16"
     sharded = None
     if args.dit_fsdp and world > 1:
         sharded = model.shard_blocks(None)  # all ranks hold the same model: FULL_SHARD over the world
@@ -321,7 +325,7 @@ def main():
         "config": {"workload": f"Wan2.1-{args.model} DiT, {n_quant} Linears W8A8{f' of which {n_w4} W4A8 (packed 4-bit weights)' if n_w4 else ''} (W asym per-channel static, A sym per-token dynamic; "
                                f"ViDiT-Q scale+rotate alpha=0.5665 on {n_vidit} self-attn q/k/v layers), "
                                f"{args.size}x{args.frames}f, latent {list(shape)}, L={seq_len}, cond+uncond+CFG+scheduler per step",
-                   "quant_config": args.quant_config, "attention": "bf16", "parallelism": plan.describe(),
+                   "quant_config": args.quant_config, "attention": attn_desc, "parallelism": plan.describe(),
                    "dit_fsdp": None if sharded is None else {"ranks": sharded.P, "block_weight_MB_per_rank": round(sharded.bytes_per_rank() / 1e6, 1),
                                                              "of_MB": round(len(sharded.blocks) * sharded.full_bytes / 1e6, 1)},
                    "launch": "hip graph replay of the two DiT passes + 1 fused CFG/scheduler kernel" if graphed is not None else
@@ -336,6 +340,8 @@ def main():
     wkey = f"{args.model} {args.size} {args.frames}f n{world}"
     g_traffic, g_src = pmc_traffic("gemm", wkey)
     a_traffic, a_src = pmc_traffic("attention", wkey)
+    if attn_desc != "bf16" and a_traffic is not None:
+        a_traffic, a_src = None, a_src + " was taken on the bf16 attention kernel, not on this run's attention configuration"
     if gs:
         ach = gs["ops"] / gs["seconds"]
         lines.append({"bound": "mfma", "kernel": "gemm_w8a8_big_kernel / gemm_w8a8_kernel (int8 MFMA, every W8A8 linear)",
@@ -345,7 +351,7 @@ def main():
     asum = atimer.summary()
     if asum:
         ach = asum["ops"] / asum["seconds"]
-        lines.append({"bound": "mfma", "kernel": "attn_fwd_kernel (bf16 MFMA flash attention, self + cross)", "achieved": ach / 1e12,
+        lines.append({"bound": "mfma", "kernel": "attn_fwd_kernel (bf16 MFMA flash attention, self + cross)" if attn_desc == "bf16" else f"attn_fwd_kernel ({attn_desc})", "achieved": ach / 1e12,
                       "peak": BF16_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK,
                       "traffic": a_traffic, "traffic_source": a_src, "traffic_unit": "HBM bytes per launch (PMC)",
                       "launches": asum["launches"], "avg_launch_us": asum["seconds"] / asum["launches"] * 1e6,
