@@ -76,6 +76,25 @@ def seeded_parameters_(model):
             p.copy_(r / math.sqrt(p[0].numel()))
 
 
+def seeded_layer_input(name, n, rows=8):
+    """[rows, n] activations with two outlier channels, from the layer's name."""
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32((name + ".x").encode()))
+    x = torch.randn(rows, n, generator=g)
+    x[:, [5, n - 7]] *= 10.0
+    return x
+
+
+def seeded_vidit(name, n):
+    """(act_mask fp32 [n] in [0.5, 1.5) with two outlier channels, rotation signs float64 [n]) of a ViDiT layer, from its name."""
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32((name + ".vidit").encode()))
+    act_mask = torch.rand(n, generator=g) + 0.5
+    act_mask[[3, n // 2]] *= 9.0
+    signs = (torch.randint(0, 2, (n,), generator=g) * 2 - 1).double()
+    return act_mask, signs
+
+
 def main():
     torch.set_grad_enabled(False)
     torch.set_num_threads(1)
@@ -127,8 +146,51 @@ def main():
             "ln_out": m.WanLayerNorm(256, eps=1e-6)(xr), "block0_in": bin_x, "block0_e": bin_kw["e"], "block0_context": bin_kw["context"],
             "block0_out": stages["block0_out"], "block1_out": stages["block1_out"]}
     arrs["param_names"] = np.array(sorted(n for n, _ in model.named_parameters()))
+
+    # ---- the same model in the reference's SIMULATION mode: its own qdiff package swaps the block Linears for QuantizedLinear /
+    # ViDiTQuantizedLinear (quant_layer_refactor_ with QuantWanModel's keyword arguments, W/wan/quant_wanx.py:85-97), the ViDiT
+    # layers get a channel mask and a rotation the way ptq_wanx.py:334-344 gives them (here from per-name seeds), and the
+    # fake-quantised model runs the same input.  W8A8 on all twenty block Linears, ViDiT on self-attention q / k / v.
+    sys.path.insert(0, "/root/reference/ViDiT-Q/quant_utils")
+    import torch.nn as nn
+    from omegaconf import OmegaConf
+    from qdiff.base.base_quantizer import BaseQuantizer
+    from qdiff.base.quant_model import quant_layer_refactor_, set_init_done_
+    from qdiff.quarot import quarot_utils
+    from qdiff.utils import apply_func_to_submodules
+    qcfg = OmegaConf.create({"remain_fp_regex": r"text_embedding|time_embedding|time_projection|head\.head",
+                             "weight": {"n_bits": 8, "sym": False}, "act": {"n_bits": 8, "sym": True},
+                             "viditq": {"alpha": 0.5665, "layer_name_regex": r"self_attn\.(q|k|v)$"}})
+    apply_func_to_submodules(model, class_type=nn.Linear, function=quant_layer_refactor_, name=None, parent_module=None,
+                             quant_config=qcfg, full_name=None, remain_fp_regex=qcfg.remain_fp_regex)
+    n_vidit = 0
+    for name, mod in model.named_modules():
+        if type(mod).__name__ == "ViDiTQuantizedLinear":
+            act_mask, signs = seeded_vidit(name, mod.in_features)
+            mod.get_channel_mask(act_mask)
+            mod.rotation_matrix = quarot_utils.matmul_hadU(torch.diag(signs))  # random_hadamard_matrix with the sign draw made explicit
+            mod.update_quantized_weight_rotated_and_scaled()
+            n_vidit += 1
+        if hasattr(mod, "a_quantizer") and mod.a_quantizer is not None:
+            mod.a_quantizer.module_name = name
+    apply_func_to_submodules(model, class_type=BaseQuantizer, function=set_init_done_)
+    stages.clear()
+    hq = [model.blocks[0].register_forward_hook(lambda mod, a, k, o: stages.__setitem__("qb0", o.clone()), with_kwargs=True)]
+    builtins.print = lambda *a, **k: None
+    out_q = model([x], t, [ctx], seq_len)[0]
+    builtins.print = real_print
+    hq[0].remove()
+    arrs["quant_out"], arrs["quant_block0_out"] = out_q, stages["qb0"]
+    # every quantized Linear of block 0 on its own: seeded inputs (regenerable from the layer's name) -> its simulation-mode output
+    for n_, mod in model.blocks[0].named_modules():
+        if hasattr(mod, "w_quantizer"):
+            xin = seeded_layer_input("blocks.0." + n_, mod.in_features)
+            arrs["layer_out.blocks.0." + n_] = mod(xin.unsqueeze(0))[0]
+    arrs["quant_classes"] = np.array(sorted(f"{n}={type(m).__name__}" for n, m in model.named_modules() if hasattr(m, "w_quantizer")))
+    real_print("simulation mode:", n_vidit, "ViDiT layers,", len(arrs["quant_classes"]), "quantized; out vs FP rel",
+               float((out_q - out).norm() / out.norm()))
     np.savez_compressed(os.path.join(HERE, "model_tiny.npz"), **{k: (v.detach().numpy() if torch.is_tensor(v) else v) for k, v in arrs.items()})
-    real_print("out", tuple(out.shape), float(out.abs().mean()), "block0", float(stages["block0_out"].abs().mean()), "params", len(arrs["param_names"]))
+    real_print("out", tuple(out.shape), float(out.abs().mean()), "block0", float(arrs["block0_out"].abs().mean()), "params", len(arrs["param_names"]))
 
 
 if __name__ == "__main__":

@@ -109,3 +109,146 @@ def test_wan_model_forward_vs_reference_model_py(gm):
     print(f"WanModel vs reference model.py: block 0 {e0:.2e}, block 1 {e1:.2e}, output {eo:.2e}")
     # bf16 autocast matmuls + bf16 q / k / v / P inside the HIP attention against the reference's fp32 run
     assert out.shape == (16, 3, 8, 6) and max(e0, e1, eo) < 2e-2
+
+
+def seeded_vidit(name, n):
+    """tests/golden/make_golden_model.py::seeded_vidit."""
+    g = torch.Generator().manual_seed(zlib.crc32((name + ".vidit").encode()))
+    act_mask = torch.rand(n, generator=g) + 0.5
+    act_mask[[3, n // 2]] *= 9.0
+    signs = (torch.randint(0, 2, (n,), generator=g) * 2 - 1).double()
+    return act_mask, signs
+
+
+def seeded_layer_input(name, n, rows=8):
+    """tests/golden/make_golden_model.py::seeded_layer_input."""
+    g = torch.Generator().manual_seed(zlib.crc32((name + ".x").encode()))
+    x = torch.randn(rows, n, generator=g)
+    x[:, [5, n - 7]] *= 10.0
+    return x
+
+
+def _block0_state_and_vidit():
+    from oracle import qdiff_ref as qr
+
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "wan2.1-quantization_amd"))
+    from wan.modules.model import WanAttentionBlock
+
+    blk = WanAttentionBlock("t2v_cross_attn", 256, 512, 2, (-1, -1), True, True, 1e-6)
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.blocks = torch.nn.ModuleList([blk])
+
+    seeded_parameters_(Holder())
+    sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    vidit = {}
+    for l in "qkv":
+        act_mask, signs = seeded_vidit(f"blocks.0.self_attn.{l}", 256)
+        mask = qr.vidit_channel_mask(sd[f"self_attn.{l}.weight"].numpy(), act_mask.numpy(), 0.5665)
+        vidit[f"self_attn.{l}"] = (torch.from_numpy(mask), torch.from_numpy(np.ascontiguousarray(qr.hadamard_from_signs(signs.numpy()))))
+    return sd, vidit
+
+
+def test_oracle_fake_quant_layers_and_block_vs_reference_simulation_mode(gm):
+    """The reference's SIMULATION mode -- its qdiff package swapped into its model.py by quant_layer_refactor_, masks / rotations
+    given the way ptq_wanx.py gives them -- against the oracle (W8A8 on the ten Linears, ViDiT scale + rotate on self-attention
+    q / k / v).  Layer level (each quantized Linear of block 0 on a seeded input): plain layers to fp32 rounding, ViDiT layers
+    up to a code flipping at a .5 boundary.  Block level: within the quantisation noise itself -- every re-quantisation down the
+    block turns a last-bit difference of its input into a flipped code now and then, so two faithful evaluations drift apart
+    by a fraction of the fake-quant-vs-FP gap (measured 3.8e-3 against 8.2e-3)."""
+    sd, vidit = _block0_state_and_vidit()
+    ref_blk = wr.block_from_state(sd, 2, eps=1e-6, quant=True, vidit=vidit)
+    for name in wr.LINEARS:
+        x = seeded_layer_input("blocks.0." + name, sd[name + ".weight"].shape[1])
+        out, ref = ref_blk.lin[name](x).numpy(), gm["layer_out.blocks.0." + name]
+        err = float(np.linalg.norm(out - ref) / np.linalg.norm(ref))
+        assert err < (1e-3 if name in vidit else 1e-6), (name, err)
+    x = torch.from_numpy(gm["block0_in"])[0]
+    out = ref_blk(x, torch.from_numpy(gm["block0_e"]), (3, 4, 3), 36, torch.from_numpy(gm["block0_context"])[0], wr.rope_freqs(128))
+    ref = gm["quant_block0_out"][0]
+    err = float(np.linalg.norm(out.numpy()[:36] - ref[:36]) / np.linalg.norm(ref[:36]))
+    fp_gap = float(np.linalg.norm(gm["block0_out"][0][:36] - ref[:36]) / np.linalg.norm(ref[:36]))
+    print(f"oracle fake-quant block vs reference simulation mode: {err:.2e} (fake-quant vs FP itself: {fp_gap:.2e})")
+    assert err < 0.6 * fp_gap
+
+
+@pytest.mark.gpu
+def test_qdiff_layers_vs_reference_simulation_mode_layers(gm):
+    """This repository's quantized Linears (int8 GEMM inside) on the same seeded inputs as the reference's simulation-mode layers of
+    block 0: plain QuantizedLinear 2e-5 of the output range, ViDiT layers within a flipped code."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "wan2.1-quantization_amd"))
+    from qdiff import config as qcfg
+    from qdiff.base.quant_layer import QuantizedLinear
+    from qdiff.viditq.viditq_quant_layer import ViDiTQuantizedLinear
+
+    sd, _ = _block0_state_and_vidit()
+    base = {"weight": {"n_bits": 8, "sym": False}, "act": {"n_bits": 8, "sym": True}}
+    for name in wr.LINEARS:
+        w, b = sd[name + ".weight"].cuda(), sd[name + ".bias"].cuda()
+        lin = torch.nn.Linear(w.shape[1], w.shape[0]).cuda()
+        lin.weight.data, lin.bias.data = w, b
+        if name in ("self_attn.q", "self_attn.k", "self_attn.v"):
+            ql = ViDiTQuantizedLinear(w.shape[1], w.shape[0], True, "cuda", qcfg.create(dict(base, viditq={"alpha": 0.5665, "layer_name_regex": ""})), lin)
+            act_mask, signs = seeded_vidit("blocks.0." + name, w.shape[1])
+            ql.get_channel_mask(act_mask.cuda())
+            ql.rotation_signs = signs
+            ql.update_quantized_weight_rotated_and_scaled()
+            tol = 5e-3
+        else:
+            ql = QuantizedLinear(w.shape[1], w.shape[0], True, "cuda", qcfg.create(base), lin)
+            tol = 2e-5
+        ql.w_quantizer.init_done = True
+        x = seeded_layer_input("blocks.0." + name, w.shape[1]).cuda()
+        out, ref = ql(x.unsqueeze(0))[0].float().cpu().numpy(), gm["layer_out.blocks.0." + name]
+        assert np.abs(out - ref).max() < tol * np.abs(ref).max() + tol, (name, float(np.abs(out - ref).max()), float(np.abs(ref).max()))
+
+
+@pytest.mark.gpu
+def test_kernel_mode_model_vs_reference_simulation_mode(gm):
+    """The whole quantized model of this repository -- simulation mode (qdiff modules) and kernel mode (HIP blocks) -- against the
+    reference's simulation-mode output on the same input, parameters, masks and rotations."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "wan2.1-quantization_amd"))
+    from qdiff import config as qcfg
+    from qdiff.base.quant_layer import QuantizedLinear
+    from wan.modules.model import WanModel
+    from wan.quant_wanx import QuantWanModel
+
+    torch.manual_seed(0)
+    with torch.device("cuda"):
+        fp = WanModel(model_type="t2v", patch_size=(1, 2, 2), text_len=32, in_dim=16, dim=256, ffn_dim=512, freq_dim=64, text_dim=64,
+                      out_dim=16, num_heads=2, num_layers=2, eps=1e-6).eval()
+    seeded_parameters_(fp)
+    cfg = qcfg.create({"remain_fp_regex": r"text_embedding|time_embedding|time_projection|head\.head",
+                       "weight": {"n_bits": 8, "sym": False}, "act": {"n_bits": 8, "sym": True},
+                       "viditq": {"alpha": 0.5665, "layer_name_regex": r"self_attn\.(q|k|v)$"}})
+    model = QuantWanModel.from_float(fp, cfg)
+    model.quant_layer_refactor()
+    classes = sorted(f"{n}={type(m).__name__}" for n, m in model.named_modules() if isinstance(m, QuantizedLinear))
+    assert classes == list(gm["quant_classes"])  # the same twenty layers, the same six ViDiT ones
+    for name, mod in model.named_modules():
+        if type(mod).__name__ == "ViDiTQuantizedLinear":
+            act_mask, signs = seeded_vidit(name, mod.in_features)
+            mod.get_channel_mask(act_mask.cuda())
+            mod.rotation_signs = signs
+            mod.update_quantized_weight_rotated_and_scaled()
+    model.set_init_done()
+    model.eval()
+    x, ctx, t = (torch.from_numpy(gm[k]).cuda() for k in ("in_x", "in_ctx", "in_t"))
+    ref, ref_fp = gm["quant_out"], gm["out"]
+
+    def rel(a, b):
+        return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        sim = model([x], t, [ctx], int(gm["seq_len"]))[0].float().cpu().numpy()
+    model.hardware_forward_refactor()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        hw = model([x], t, [ctx], int(gm["seq_len"]))[0].float().cpu().numpy()
+    print(f"vs the reference's simulation mode: ours simulation {rel(sim, ref):.2e}, ours kernel mode {rel(hw, ref):.2e}; "
+          f"(reference quantized vs reference FP {rel(ref, ref_fp):.2e})")
+    # model level: two faithful evaluations of the same fake-quant recipe drift apart by a fraction of the quantisation noise
+    # (every re-quantisation flips a code now and then; bf16 attention on top): bar = the reference's own quantized-vs-FP gap
+    gap = rel(ref, ref_fp)
+    assert rel(sim, ref) < 1.5 * gap and rel(hw, ref) < 1.5 * gap and rel(hw, ref_fp) < 2.5 * gap
