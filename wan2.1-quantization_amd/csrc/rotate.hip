@@ -185,11 +185,13 @@ __device__ __forceinline__ void hadamard_regs(float (&v)[KIN][EPL], int lane, fl
         }
   __builtin_amdgcn_sched_barrier(0);
   // ... then bits of c (lane bits 0 .. log2(LB)-1)
+#ifndef WANQ_ROT_ABLATE_LANE  // (WANQ_ROT_ABLATE_*: timing probes only, tools/probes/rotate_ablate.py; never defined in the product build)
   lane_stage<1, KIN, EPL>(v, lane);
   lane_stage<2, KIN, EPL>(v, lane);
   lane_stage<4, KIN, EPL>(v, lane);
   lane_stage<8, KIN, EPL>(v, lane);
   if constexpr (LB >= 32) lane_stage<16, KIN, EPL>(v, lane);
+#endif
   __builtin_amdgcn_sched_barrier(0);
   // M_KIN across this lane's blocks
   if constexpr (is_pow2_c(KIN)) {
@@ -206,6 +208,7 @@ __device__ __forceinline__ void hadamard_regs(float (&v)[KIN][EPL], int lane, fl
           }
         }
   } else {
+#ifndef WANQ_ROT_ABLATE_MIX
     constexpr MixTable<KIN> tab{};
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
@@ -221,6 +224,7 @@ __device__ __forceinline__ void hadamard_regs(float (&v)[KIN][EPL], int lane, fl
       for (int a = 0; a < KIN; ++a) v[a][j] = t[a];
       __builtin_amdgcn_sched_barrier(0);
     }
+#endif
   }
   // S_Q (Sylvester) across the lane groups of the row
   if constexpr (Q >= 2) lane_stage<LB, KIN, EPL>(v, lane);
@@ -409,7 +413,11 @@ __global__ __launch_bounds__(256, rot_waves_per_simd(KIN* EPL)) void rotate_kern
 #pragma unroll
     for (int r = 0; r < KIN; ++r) {
       int qi[EPL];
+#ifdef WANQ_ROT_ABLATE_QUANT
+      for (int j = 0; j < EPL; ++j) qi[j] = (int)(v[r][j] * inv);
+#else
       quantN_div_rne<EPL>(v[r], scale, inv, qi);
+#endif
       int8_t* dst = q8 + rbase + col0 + 128 * r;
       const uint32_t lo = pack4_i8_fast(qi[0], qi[1], qi[2], qi[3]);
       isum = __builtin_amdgcn_sdot4((int)lo, 0x01010101, isum, false);  // sum of the four signed bytes
