@@ -331,7 +331,7 @@ constexpr int rot_waves_per_simd(int row_regs) { return row_regs <= 8 ? 4 : row_
 // normalised row again from x for every set after the first (the wave has just read it: L1 / L2 hits) instead of keeping
 // a second copy in registers.
 template <int KIN, int Q, int EPL, bool LN, bool MULTI>
-__global__ __launch_bounds__(256, rot_waves_per_simd(KIN* EPL)) void rotate_kernel(const RotParams p) {
+__global__ __launch_bounds__(256, rot_waves_per_simd(KIN* EPL * ((MULTI && KIN * EPL <= 48 && Q == 1) ? 2 : 1))) void rotate_kernel(const RotParams p) {
   constexpr int LB = 128 / EPL, LPR = LB * Q, RPW = 64 / LPR;
   static_assert(LPR <= 64, "a row must fit one wave");
   const int lane = threadIdx.x & 63;
@@ -368,6 +368,16 @@ __global__ __launch_bounds__(256, rot_waves_per_simd(KIN* EPL)) void rotate_kern
     rot_normalise<KIN, EPL>(p, col0_k, mb, mean, rstd, v);
   }
 
+  // MULTI with few floats per lane (KIN * EPL <= 48): the normalised row is KEPT in a second register copy for outputs 2 and 3
+  // instead of being re-read and re-normalised (ablation: 147 of the call's 236 us are load / LayerNorm / re-read / stores)
+  constexpr bool KEEP = MULTI && KIN * EPL <= 48 && Q == 1;
+  float vn[KEEP ? KIN : 1][KEEP ? EPL : 1];
+  if constexpr (KEEP) {
+#pragma unroll
+    for (int r = 0; r < KIN; ++r)
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) vn[r][j] = v[r][j];
+  }
   const int nsets = MULTI ? p.nsets : 1;
 #pragma unroll
   for (int set = 0; set < (MULTI ? 3 : 1); ++set) {
@@ -378,8 +388,15 @@ __global__ __launch_bounds__(256, rot_waves_per_simd(KIN* EPL)) void rotate_kern
     int64_t rbase = rbase_k;
     if (MULTI) asm volatile("" : "+v"(col0), "+v"(rbase));
     if (MULTI && set > 0) {
-      rot_load_row<KIN, EPL>(p.x, p.x_dtype, rbase + col0, v);
-      rot_normalise<KIN, EPL>(p, col0, mb, mean, rstd, v);
+      if constexpr (KEEP) {
+#pragma unroll
+        for (int r = 0; r < KIN; ++r)
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) v[r][j] = vn[r][j];
+      } else {
+        rot_load_row<KIN, EPL>(p.x, p.x_dtype, rbase + col0, v);
+        rot_normalise<KIN, EPL>(p, col0, mb, mean, rstd, v);
+      }
     }
     const float* premul = p.premul[set];
     if (premul) {
