@@ -85,3 +85,30 @@ def test_four_entry_points_at_headline_size(tmp_path):
     print(f"headline size, 3 steps: quantized kernel mode vs FP rel L2 {rel:.3e}")
     assert q.shape == fp.shape and torch.isfinite(q).all() and rel < 5e-2
     assert "int_weight" in log  # the kernel-mode blocks were loaded from the exported checkpoint
+
+
+def test_quant_generate_two_ranks_ulysses_and_dit_fsdp(tmp_path):
+    """The entry script itself under two ranks (one-GPU rehearsal: gloo rendezvous, host-staged collectives): `quant_generate.py
+    --ulysses_size 2 --dit_fsdp` -- sequence-parallel kernel-mode blocks with their integer weights sharded over the two ranks --
+    reproduces the single-rank latent of the same checkpoint bit for bit."""
+    import socket
+
+    qc = os.path.join(PKG, "quant_configs", "w8a8_all_linears.yaml")
+    calib = str(tmp_path / "calib.pth")
+    run("fp_generate.py", cwd=tmp_path)
+    run("get_calib_data_wanx.py", "--quant_config", qc, "--calib_data", calib, cwd=tmp_path)
+    run("ptq_wanx.py", "--quant_config", qc, "--calib_data", calib, cwd=tmp_path)
+    run("quant_generate.py", "--quant_config", qc, "--save_file", str(tmp_path / "one.pt"), cwd=tmp_path)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(PKG, "quant_generate.py"), "--task", "t2v-1.3B", "--size", "832*480", "--frame_num", "5",
+           "--num_layers", "2", "--sample_steps", "2", "--base_seed", "42", "--output_dir", str(tmp_path), "--quant_config", qc,
+           "--ulysses_size", "2", "--dit_fsdp", "--save_file", str(tmp_path / "two.pt")]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp_path, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="4", WANQ_REHEARSE_ON_ONE_GPU="1"))
+    assert r.returncode == 0, f"two-rank quant_generate failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+    assert "dit_fsdp:" in r.stdout + r.stderr and "cfg1xsp2" in r.stdout + r.stderr
+    one = torch.load(tmp_path / "one.pt", weights_only=True)
+    two = torch.load(tmp_path / "two.pt", weights_only=True)
+    assert torch.equal(one, two)

@@ -81,10 +81,20 @@ def setup_distributed(args, num_heads):
     from .distributed.parallel import ParallelPlan
 
     rank, world, local = int(os.getenv("RANK", 0)), int(os.getenv("WORLD_SIZE", 1)), int(os.getenv("LOCAL_RANK", 0))
+    # Rehearsal of the multi-rank control flow on a ONE-GPU box (RCCL refuses two ranks on one device): every rank uses cuda:0,
+    # the rendezvous is gloo and the collectives are staged through host memory (wan/distributed/rehearsal.py).  Never a product mode.
+    rehearse = world > 1 and os.getenv("WANQ_REHEARSE_ON_ONE_GPU") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
-    if world > 1:
+    if rehearse:
+        dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
+        from .distributed.rehearsal import stage_collectives_through_host
+        stage_collectives_through_host()
+    elif world > 1:
         dist.init_process_group(backend="nccl", init_method="env://", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local))
+    if world > 1:
         seed = [args.base_seed] if rank == 0 else [None]
         dist.broadcast_object_list(seed, src=0)
         args.base_seed = seed[0]
