@@ -81,3 +81,61 @@ for (rows, H) in [(270, 4), (4680, 12)]:
     w = torch.rand(H * 128, device=DEV, generator=g) + 0.5
     rope = torch.randn(rows, 64, 2, device=DEV, generator=g)
     check(f"rmsnorm_rope       [{rows},{H*128}]", lambda: ops.rmsnorm_rope_(x.clone(), w, rope, 128, eps=1e-6))
+
+# ---- round 2 kernels: int8-QK attention, per-head int8 form, scattered store, W4A8 GEMM, 8960 transform, column fake-quant,
+# fused step
+for (Lq, Lk, H) in [(270, 270, 4), (4680, 4680, 12), (300, 5000, 1)]:
+    w = torch.rand(H * 128, device=DEV, generator=g) + 0.5
+    rope = torch.randn(max(Lq, Lk), 64, 2, device=DEV, generator=g)
+    xq = torch.randn(Lq, H * 128, device=DEV, generator=g).to(torch.bfloat16)
+    xk = torch.randn(Lk, H * 128, device=DEV, generator=g).to(torch.bfloat16)
+    v = torch.randn(Lk, H * 128, device=DEV, generator=g).to(torch.bfloat16)
+
+    def qk8():
+        q8 = ops.rmsnorm_rope_q8(xq, w, rope[:Lq].contiguous(), 128, False)
+        k8 = ops.rmsnorm_rope_q8(xk, w, rope[:Lk].contiguous(), 128, True)
+        return [q8.codes, q8.scales, k8.codes, k8.scales, ops.attention_qk8(q8, k8, v, H)]
+
+    check(f"rmsnorm_rope_q8 + attention_qk8 Lq={Lq} Lk={Lk} H={H}", qk8)
+
+from wan.distributed.parallel import SeqParallel  # noqa: E402
+sp = SeqParallel(False)
+sp.size = 4
+x = torch.randn(1170, 1536, device=DEV, generator=g).to(torch.bfloat16)
+w = torch.rand(1536, device=DEV, generator=g) + 0.5
+rope = torch.randn(1170, 64, 2, device=DEV, generator=g)
+numel, hmap, _ = sp.packed_layout(1170, 1536, 128, [(0, 128), (128, 384)], DEV)
+check("rmsnorm_rope_scatter [1170,1536] P=4", lambda: ops.rmsnorm_rope_scatter(x, w, rope, 128, torch.zeros(numel, dtype=torch.bfloat16, device=DEV), hmap))
+
+for (M, N, K) in [(270, 512, 512), (4680, 1536, 8960), (1000, 520, 1536)]:
+    a = torch.randint(-128, 128, (M, K), dtype=torch.int8, device=DEV, generator=g)
+    wp = qgemm.pack_w4(torch.randint(-8, 8, (N, K), dtype=torch.int8, device=DEV, generator=g), bias=8)
+    sa, asum = torch.rand(M, device=DEV, generator=g) * 0.01, torch.rand(M, device=DEV, generator=g)
+    sw, zp, bias = torch.rand(N, device=DEV, generator=g) * 0.01, torch.randn(N, device=DEV, generator=g), torch.randn(N, device=DEV, generator=g)
+    check(f"gemm W4A8 {M}x{N}x{K} bf16", lambda: qgemm.w8a8_linear(a, wp, sa, sw, bias, asum, zp, out_dtype=torch.bfloat16, w4=True))
+
+hb = torch.randn(2340, 8960, device=DEV, generator=g).to(torch.bfloat16)
+pm = torch.randn(8960, device=DEV, generator=g)
+rot = qu.kernel_rotation_params(8960, DEV)
+
+
+def r140():
+    s_, u_ = torch.zeros(2340, device=DEV), torch.zeros(2340, device=DEV)
+    return [fused.rotate_quant(hb, pm, rot, u_, s_), s_, u_]
+
+
+check("rotate(140x64)+quant [2340,8960]", r140)
+vv = torch.randn(4680, 1536, device=DEV, generator=g).to(torch.bfloat16)
+check("col_absmax + fake_quant_cols [4680,1536]", lambda: list(fused.fake_quant_cols_(vv.clone(), 8)))
+from wan.utils.fused_step import lincomb  # noqa: E402
+ins = [torch.randn(16 * 21 * 60 * 104, device=DEV, generator=g) for _ in range(6)]
+coef = torch.randn(3, 6).numpy()
+
+
+def lc():
+    outs = [torch.empty_like(ins[0]) for _ in range(3)]
+    lincomb(coef, ins, outs)
+    return outs
+
+
+check("lincomb 3 x 6 latent-sized", lc)
