@@ -58,6 +58,40 @@ def test_bad_arguments_are_refused_with_message(lib):
     assert rc == 2 and b"K=24" in lib.wanq_last_error()
 
 
+def test_round2_entry_points_refuse_bad_arguments(lib):
+    """Argument checks of the entry points added in ABI version 2 run on the host, before any launch: return code + message."""
+    lib.wanq_last_error.restype = ctypes.c_char_p
+    i64 = ctypes.c_int64
+    buf = ctypes.create_string_buffer(256)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.wanq_abi_version() == 2
+    # W4A8: K must hold whole 32-code groups
+    rc = lib.wanq_gemm_w4a8(p, p, p, 0, p, None, 0, p, None, 0, None, 0, None, None, 0, i64(8), 16, 48, None)
+    assert rc == 2 and b"K=48" in lib.wanq_last_error()
+    # the 8960 transform: had_k = 140 only goes with cols = 8960; the LayerNorm form has no such variant
+    rc = lib.wanq_rotate_quant_rows(p, 2, None, 140, p, 2, None, None, None, 2, i64(4), 1536, None)
+    assert rc == 2 and b"8960" in lib.wanq_last_error()
+    rc = lib.wanq_layernorm_rotate_quant_rows(p, 2, None, None, None, 2, i64(0), i64(4), ctypes.c_float(1e-6), None, 140, p, p, p, 2, i64(4), 8960, None)
+    assert rc == 2 and b"8960" in lib.wanq_last_error()
+    # scattered RMSNorm+RoPE store needs its head map
+    rc = lib.wanq_rmsnorm_rope_scatter(p, 1, p, None, p, 1, None, i64(4), 256, 128, i64(4), i64(0), ctypes.c_float(1e-6), None)
+    assert rc == 1 and b"NULL" in lib.wanq_last_error()
+    # column fake-quant: bit-width range
+    rc = lib.wanq_fake_quant_cols(p, 2, p, p, 2, 9, i64(4), 64, None)
+    assert rc == 1 and b"n_bits=9" in lib.wanq_last_error()
+    # fused step: at most 4 outputs of at most 8 inputs, 16-byte aligned tensors of numel % 4 == 0
+    arr = (ctypes.c_void_p * 1)(p)
+    coef = (ctypes.c_float * 1)(1.0)
+    rc = lib.wanq_lincomb(5, 1, coef, arr, arr, i64(16), None)
+    assert rc == 1 and b"n_out=5" in lib.wanq_last_error()
+    rc = lib.wanq_lincomb(1, 1, coef, arr, arr, i64(6), None)
+    assert rc == 2 and b"numel=6" in lib.wanq_last_error()
+    # int8 Q.K^T attention: head_dim 128 only
+    rc = lib.wanq_attention_qk8_fwd(p, p, i64(64), p, p, i64(64), p, p, 1, i64(64), i64(64), 2, 64, i64(128), i64(128), i64(128), i64(128),
+                                    ctypes.c_float(0.1), 1, None, i64(0), None)
+    assert rc != 0 and lib.wanq_last_error()
+
+
 def test_reference_module_surface():
     import viditq_extension.fused as fused
     import viditq_extension.qgemm as qgemm
