@@ -356,6 +356,15 @@ def main():
                       "traffic": a_traffic, "traffic_source": a_src, "traffic_unit": "HBM bytes per launch (PMC)",
                       "launches": asum["launches"], "avg_launch_us": asum["seconds"] / asum["launches"] * 1e6,
                       "share_of_step": asum["seconds"] / dt_prof})
+    # whole-step int8 matrix work against the int8 MFMA roofline (north star: "throughput ... as fraction of the int8-MFMA roofline"):
+    # every W8A8 / W4A8 GEMM of the step, plus the Q.K^T half of the attention FLOPs where that runs on the int8 matrix cores
+    # (attn.qk configs).  With bf16 attention (the reference's Wan wiring) most of the step's time is not int8 work at all.
+    if gs:
+        qk_share = sum(1 for b_ in model.hip_blocks for f_ in (b_.attn_qk8,) if f_) / max(1, len(model.hip_blocks))
+        int8_ops = gs["ops"] / args.steps + (0.5 * asum["ops"] / args.steps * qk_share if (asum and qk_share) else 0.0)
+        out["int8_step"] = {"int8_ops_per_step": int8_ops, "achieved_TOPs": int8_ops * args.steps / dt / 1e12,
+                            "frac_of_int8_mfma_peak": int8_ops * args.steps / dt / INT8_MFMA_PEAK,
+                            "what": "all int8 MFMA work of a step / the step's wall time / 5.03 POP/s"}
     lines.sort(key=lambda r: -r["share_of_step"])
     if lines:
         out["roofline"] = lines[0]
