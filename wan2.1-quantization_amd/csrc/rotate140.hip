@@ -66,8 +66,8 @@ __device__ __forceinline__ void r140_load_row(const void* x, int64_t rbase, int 
     }
   }
 }
-// 16-bit inputs: the raw 16-B chunks of the NEXT row are requested as soon as this row's have been converted, and stay in
-// flight (20 registers) under the whole transform / MFMA / quantise sequence of this row
+// 16-bit inputs: the row's raw 16-B chunks.  (Requesting the NEXT row's chunks a row ahead was tried: the 20 registers they pin beside
+// the 108 of A make hipcc spill, and a spill reload waits vmcnt(0), i.e. for that very prefetch -- 717 us with it, 664 us without.)
 __device__ __forceinline__ void r140_load_raw16(const void* x, int64_t rbase, int tid, uint4 (&raw)[R140_PASSES]) {
 #pragma unroll
   for (int ps = 0; ps < R140_PASSES; ++ps) {
@@ -149,8 +149,6 @@ __global__ __launch_bounds__(256, 2) void rotate140_kernel(const Rot140Params p)
 
   const int tid_k = tid;
   const bool x16 = p.x_dtype != WANQ_F32;
-  uint4 raw[R140_PASSES];
-  if (x16 && (int64_t)blockIdx.x < p.rows) r140_load_raw16(p.x, (int64_t)blockIdx.x * R140_N, tid, raw);
   for (int64_t row = blockIdx.x; row < p.rows; row += gridDim.x) {
     const int64_t rbase = row * (int64_t)R140_N;
     // keep the per-pass addresses of x / premul / out / q out of loop-invariant motion: hoisted, their 64-bit copies for every
@@ -162,10 +160,10 @@ __global__ __launch_bounds__(256, 2) void rotate140_kernel(const Rot140Params p)
     if (tid < 96) *reinterpret_cast<uint4*>(smem + (tid >> 5) * R140_PLANE + 140 * 128 + (tid & 31) * 16) = make_uint4(0, 0, 0, 0);
     float v[R140_PASSES][8];
     if (x16) {
+      uint4 raw[R140_PASSES];
+      r140_load_raw16(p.x, rbase, tid, raw);
       if (p.x_dtype == WANQ_BF16) r140_unpack16<true>(raw, v);
       else r140_unpack16<false>(raw, v);
-      const int64_t nxt = row + gridDim.x;
-      if (nxt < p.rows) r140_load_raw16(p.x, nxt * R140_N, tid, raw);
     } else {
       r140_load_row<F32>(p.x, rbase, tid, v);
     }
