@@ -528,8 +528,14 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
     // bytes).  Each wave therefore turns its results through a private 4-KiB LDS buffer (32 tokens x 128 B, 16-B chunks
     // XORed with row&7; stage 1 is free until the next tile's second K-tile) and stores -- and reads the residual --
     // as whole 128-B lines, 8 lanes per line.  Same-wave LDS traffic only: no barrier.
+    // (the lane-derived constants of the store loop are taken from an OPAQUE copy of the lane id: derived from `lane` itself they
+    // are loop-invariant, hipcc keeps them live across the main loop -- which sits at the 256-register cap -- and spills them; every
+    // reload in the store loop then carries s_waitcnt vmcnt(0), i.e. waits for the next tile's LDS-DMA and for the acknowledgement
+    // of the stores issued so far)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
     char* tb = smem + B2_STAGE + 4096 + wave * 4096;
-    const int rd_row = lane >> 3, rd_c = lane & 7;  // read-back: row rd_row + 8*pass, 16-B chunk rd_c
+    const int rd_row = lane_e >> 3, rd_c = lane_e & 7;  // read-back: row rd_row + 8*pass, 16-B chunk rd_c
     const int tok_base = cur_m0 + wm * 128;
     constexpr bool OUT16 = (OUT == WANQ_F16 || OUT == WANQ_BF16);
     if (OUT16 && !has_res) {
