@@ -71,6 +71,9 @@ __device__ __forceinline__ bf16x8 at_join(s16x4 lo, s16x4 hi) {
   return __builtin_bit_cast(bf16x8, vv);
 }
 
+#ifdef WANQ_CLOCK_PROBE  // diagnostic build only: shader clock held by one workgroup (clock64 ticks per 100-MHz wall tick)
+__device__ unsigned long long g_clk[2];
+#endif
 #ifdef WANQ_ATTN_STAMP
 __device__ unsigned long long g_stamp[8 * 16];
 #define STAMP(i) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); acc_[i] += t_ - last_; last_ = t_; }
@@ -94,6 +97,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int head = blockIdx.y;
+#ifdef WANQ_CLOCK_PROBE
+  const unsigned long long clk_c0 = clock64(), clk_w0 = wall_clock64();
+#endif
   const int q0 = blockIdx.x * AT_QB + wave * AT_QW;
   const int nt = (p.Lk + AT_KB - 1) / AT_KB;
   float c = p.c;
@@ -561,6 +567,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
   }
 #endif
 
+#ifdef WANQ_CLOCK_PROBE
+  if (blockIdx.x == 70 && blockIdx.y == 3 && tid == 0) { g_clk[0] = clock64() - clk_c0; g_clk[1] = wall_clock64() - clk_w0; }
+#endif
   // ---- epilogue: O[q, d] = O^T[d, q] / l ; lane holds d = 32 db + (r&3) + 8 (r>>2) + 4 fh of query fr
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (SPLIT) {  // unnormalised partials; attn_combine_kernel merges the splits
@@ -704,6 +713,14 @@ static int attention_impl(const void* q, const void* k, const void* v, void* o, 
     } else {
       launch_attn<false, false>(p, grid, st);
     }
+#ifdef WANQ_CLOCK_PROBE
+    {
+      (void)hipStreamSynchronize((hipStream_t)stream);
+      unsigned long long h[2];
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_clk), sizeof(h));
+      printf("[clock] attention Lq=%lld Lk=%lld: %llu cycles in %.1f us -> %.0f MHz\n", (long long)Lq, (long long)Lk, h[0], h[1] / 100.0, h[0] / (h[1] / 100.0));
+    }
+#endif
 #ifdef WANQ_ATTN_STAMP
     {
       (void)hipStreamSynchronize((hipStream_t)stream);

@@ -285,28 +285,32 @@ __global__ __launch_bounds__(256, 2) void gemm_w8a8_kernel(const GemmParams p) {
 
 // =====================================================================================================
 // v2 (large M): persistent kernel, 256(M) x 256(N) tile, 8 waves as 2(M) x 4(N), each wave 128 tokens x 64
-// channels = 4 x 2 MFMA tiles (6 ds_read_b128 per 8 MFMAs).
+// channels = 8 x 4 blocks of v_mfma_i32_16x16x64_i8 (12 ds_read_b128 per 32 MFMAs).
+//  * MFMA shape: the 16x16x64 form does the same work per cycle as 32x32x32 but the part holds a higher clock under it (the
+//    chip is clock/power-limited in this kernel: 1.45-1.85 GHz measured inside it, tools/probes/clock_probe_run.py; bare
+//    streams: 4.25 vs 3.74 POP/s, tools/probes/mfma_shape_clock.hip).  Same LDS bytes per MFMA cycle, same LDS image.
 //  * Both operands go global -> LDS directly (global_load_lds_dwordx4, 16 B per lane, one 1-KiB wave
 //    instruction = 8 rows x 128 B); the LDS image stays lane-linear and the bank swizzle is applied on the
 //    per-lane SOURCE address (and on the fragment reads).
 //  * Two 64-KiB stages: the loads of K-tile t+1 are issued right after the barrier that publishes tile t and
-//    fly under its 32 MFMAs per wave (one barrier per K tile); inside a K tile the fragments of k-step s+1 are
-//    read while the MFMAs of k-step s issue (register double buffer).
+//    fly under its 64 MFMAs per wave (one barrier per K tile); inside a K tile the fragments of MFMA block b+1 are
+//    read while the MFMAs of block b issue (register double buffer).
 //  * One workgroup per CU walks its tiles: the first K-tile of the NEXT output tile is requested before the
 //    epilogue of the current one, and the wait that publishes it is a COUNTED s_waitcnt vmcnt(#epilogue
 //    stores), so the epilogue's stores drain to HBM underneath the next tile's main loop instead of stalling
 //    every CU at the same time.
 // Used when M >= 512 and K % 128 == 0; everything else takes the v1 kernel.
+#ifdef WANQ_CLOCK_PROBE  // diagnostic build only: shader clock held by one workgroup of the persistent kernel
+__device__ unsigned long long g_gemm_clk[2];
+#endif
 constexpr int B2M = 256, B2N = 256, B2K = 128;
 constexpr int B2_STAGE = (B2M + B2N) * B2K;  // 64 KiB
 
 // W4 (packed 4-bit weights, wanq_pack_w4 layout): a K-tile of the weight panel is 256 rows x 64 B = 16 KiB instead of 32 (two
-// LDS-DMA instructions per wave instead of four: the weight half of the ingest stream -- the loop's limiter -- halves); a lane
-// reads 16 packed bytes = 32 codes with ONE ds_read_b128 and expands them in registers (and / shift+and) into the MFMA operands
-// of two k-steps.  The k order inside a K-tile is therefore: k-step 2t+u, lane half fh <-> 16-byte activation chunk
-// 4t + 2fh + u (any bijection works as long as both operands use it).  LDS image of the packed panel: 64-B rows, 16-B pieces
-// XORed with (row>>2)&3 (conflict-free for the b128 lane groups, and a whole 16-B piece moves, so the DMA source stays 16 B
-// contiguous).
+// LDS-DMA instructions per wave instead of four: the weight half of the ingest stream halves); a lane reads the 8 packed bytes
+// = 16 codes of its operand with ONE ds_read_b64 and expands them in registers (and / shift+and).  LDS image of the packed
+// panel: 64-B rows, 16-B pieces XORed with (row>>2)&3 (conflict-free for the b64 lane groups, and a whole 16-B piece moves, so
+// the DMA source stays 16 B contiguous).
 template <int OUT, bool W4>
 __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -315,6 +319,9 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 1, wn = wave >> 1;
+#ifdef WANQ_CLOCK_PROBE
+  const unsigned long long clk_c0 = clock64(), clk_w0 = wall_clock64();
+#endif
   const int fr = lane & 31, fh = lane >> 5;
   const int K = p.K;
   const int nk = K / B2K;
@@ -355,28 +362,39 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
       }
     }
   };
-#define B2_ISSUE(kt, stage)                                                                              \
-  do {                                                                                                   \
-    char* sx_ = smem + (stage) * B2_STAGE + wave * 1024;                                                 \
-    const int8_t* ak_ = p.a + (kt) * B2K;                                                                \
-    const int8_t* wk_ = p.w + (kt) * (W4 ? B2K / 2 : B2K);                                               \
-    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                      \
-      __builtin_amdgcn_global_load_lds((glb_void*)(ak_ + srcx[g]), (lds_void*)(sx_ + g * 8192), 16, 0, 0); \
-      if (!W4 || g < 2)                                                                                  \
-        __builtin_amdgcn_global_load_lds((glb_void*)(wk_ + srcw[g]), (lds_void*)(sx_ + B2M * B2K + g * 8192), 16, 0, 0); \
-    }                                                                                                    \
+  // piece idx = 2 g + isW: instruction g of the activation tile / of the weight tile (W4: the packed panel has pieces g < 2 only)
+#define B2_PIECE(kt, stage, idx)                                                                              \
+  do {                                                                                                        \
+    char* sx_ = smem + (stage) * B2_STAGE + wave * 1024 + ((idx) >> 1) * 8192;                                \
+    if (((idx) & 1) == 0)                                                                                     \
+      __builtin_amdgcn_global_load_lds((glb_void*)(p.a + (kt) * B2K + srcx[(idx) >> 1]), (lds_void*)sx_, 16, 0, 0); \
+    else if (!W4 || (idx) < 4)                                                                                \
+      __builtin_amdgcn_global_load_lds((glb_void*)(p.w + (kt) * (W4 ? B2K / 2 : B2K) + srcw[(idx) >> 1]),    \
+                                       (lds_void*)(sx_ + B2M * B2K), 16, 0, 0);                               \
+  } while (0)
+#define B2_ISSUE(kt, stage)                                                   \
+  do {                                                                        \
+    _Pragma("unroll") for (int x_ = 0; x_ < 8; ++x_) B2_PIECE(kt, stage, x_); \
   } while (0)
 
-  // fragment reads: W rows wn*64 + i*32 + fr, X rows wm*128 + j*32 + fr.  The row swizzle (row>>1)&7 equals
-  // (fr>>1)&7 for every i / j, so one chunk offset per k-step serves all six reads (i, j become immediates).
-  const int fsw = (fr >> 1) & 7;
-  int ck[4];
+  // fragment reads for v_mfma_i32_16x16x64_i8: lane (r16 = lane & 15, q4 = lane >> 4) holds 16 consecutive k of row r16 of a
+  // 16-row block: W rows wn*64 + 16 i + r16 (A operand), X rows wm*128 + 16 j + r16 (B operand), 16-B chunk 4 ks + q4 of the
+  // 128-B K-tile row.  The row swizzle (row>>1)&7 equals (r16>>1)&7 for every i / j, so one chunk offset per k-step serves all
+  // twelve reads (i, j become immediates); a b128 lane group {0-3, 12-15 | 20-27} then covers all 16 slots of a bank row.
+  // W4: the 16 codes of chunk c are the 8 packed bytes at half (c & 1) of 16-B piece c >> 1 of the 64-B packed row (one
+  // ds_read_b64 per operand, conflict-free: a 32-lane half reads 16 rows x one whole piece).
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int fsw = (r16 >> 1) & 7;
+  int ck[2], cw4[2];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) ck[ks] = (((W4 ? 4 * (ks >> 1) + 2 * fh + (ks & 1) : 2 * ks + fh)) ^ fsw) << 4;
-  const int rowx = (wm * 128 + fr) * B2K;
-  const int roww = B2M * B2K + (wn * 64 + fr) * (W4 ? B2K / 2 : B2K);
-  const int cq0 = ((0 + fh) ^ ((fr >> 2) & 3)) << 4, cq1 = ((2 + fh) ^ ((fr >> 2) & 3)) << 4;  // W4: packed piece of t = 0, 1
+  for (int ks = 0; ks < 2; ++ks) {
+    ck[ks] = ((4 * ks + q4) ^ fsw) << 4;
+    cw4[ks] = (((2 * ks + (q4 >> 1)) ^ ((r16 >> 2) & 3)) << 4) + 8 * (q4 & 1);
+  }
+  const int rowx = (wm * 128 + r16) * B2K;
+  const int roww = B2M * B2K + (wn * 64 + r16) * (W4 ? B2K / 2 : B2K);
 
+  const bool dma_top = !W4 && nk >= 32;
   int tile = blockIdx.x;
   if (tile >= ntiles) return;
   int m0, n0;
@@ -386,13 +404,14 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
   int pending_stores = 0;  // epilogue store instructions issued after the loads now in flight
 
   for (;;) {
-    v16i acc[2][4];
+    // acc[i][j][e]: channel n0 + wn*64 + 16 i + 4 q4 + e, token m0 + wm*128 + 16 j + r16
+    v4i acc[4][8];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 8; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0;
 
     for (int kt = 0; kt < nk; ++kt) {
       // publish K-tile kt: my LDS-DMA for it has landed (everything older than the last `pending_stores`
@@ -404,67 +423,57 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
       pending_stores = 0;
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      if (kt + 1 < nk) B2_ISSUE(kt + 1, (kt + 1) & 1);
+      const bool more = kt + 1 < nk;
+      if (more && dma_top) B2_ISSUE(kt + 1, (kt + 1) & 1);
+      const bool more_spread = more && !dma_top;
       const char* st = smem + (kt & 1) * B2_STAGE;
-      v4i xf[2][4];
-      if (!W4) {
-        v4i wf[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) wf[0][i] = *reinterpret_cast<const v4i*>(st + roww + ck[0] + i * 32 * B2K);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) xf[0][j] = *reinterpret_cast<const v4i*>(st + rowx + ck[0] + j * 32 * B2K);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const int cb = ks & 1, nb = cb ^ 1;
-          if (ks < 3) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) wf[nb][i] = *reinterpret_cast<const v4i*>(st + roww + ck[ks + 1] + i * 32 * B2K);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xf[nb][j] = *reinterpret_cast<const v4i*>(st + rowx + ck[ks + 1] + j * 32 * B2K);
-          }
-          __builtin_amdgcn_sched_barrier(0);  // keep the reads of k-step s+1 AHEAD of the MFMAs of k-step s
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[cb][i], xf[cb][j], acc[i][j], 0, 0, 0);
-        }
-      } else {
-        // wq[i]: 32 packed codes of weight row block i; wa / wb[t][i]: the int8 operands of k-steps 2t and 2t+1
-        v4i wq[2], wa[2][2], wb[2][2];
-        const v4i m4 = {0x0f0f0f0f, 0x0f0f0f0f, 0x0f0f0f0f, 0x0f0f0f0f};
-#define B2_UNPACK(t)                                                                        \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                           \
-    const v4i lo_ = wq[i] & m4, hi_ = (wq[i] >> 4) & m4;                                    \
-    wa[t][i] = v4i{lo_[0], hi_[0], lo_[1], hi_[1]};                                         \
-    wb[t][i] = v4i{lo_[2], hi_[2], lo_[3], hi_[3]};                                         \
+      // A K-tile is sixteen groups of 4 MFMAs: group g = 8 ks + j multiplies the four weight fragments of k-step ks (64 deep)
+      // with the activation fragment of token block j.  Activation fragments live in a ring of four registers quads, read
+      // three groups (192 MFMA cycles) ahead of their use; the weight fragments of k-step 1 are read during k-step 0.
+      // 48 fragment registers: a block-wise double buffer (64) made hipcc spill a fragment address and reload it -- behind
+      // s_waitcnt vmcnt(0), i.e. after the prefetch had drained -- on every K-tile.
+      // The eight LDS-DMA pieces of K-tile kt+1 are either issued one per group in front of the first eight groups (short K:
+      // +2 % at K = 1536) or all at the top of the tile (long K: +4 % at K = 8960 / 13824); A/B in one process,
+      // tools/ab_gemm_variants.py.  Either way they have at least the second half of the tile plus the barrier to land.
+      v4i wf[2][4], xr[4];
+      const v4i m4 = {0x0f0f0f0f, 0x0f0f0f0f, 0x0f0f0f0f, 0x0f0f0f0f};
+#define B2_LDW(ks)                                                                                          \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                           \
+    if (!W4) wf[ks][i] = *reinterpret_cast<const v4i*>(st + roww + ck[ks] + i * 16 * B2K);                  \
+    else wraw[i] = *reinterpret_cast<const uint2*>(st + roww + cw4[ks] + i * 16 * (B2K / 2));              \
   }
+  // W4: 8 packed bytes -> the 16 codes of the operand (byte b of dword d: code 8 d + b low nibble, code 8 d + 4 + b high nibble);
+  // placed a few groups AFTER the reads so that the conversion does not wait for them
+#define B2_UNPACK(ks)                                                                                       \
+  if (W4) {                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
+      const v4i u_ = {(int)wraw[i].x, (int)(wraw[i].x >> 4), (int)wraw[i].y, (int)(wraw[i].y >> 4)};        \
+      wf[ks][i] = u_ & m4;                                                                                  \
+    }                                                                                                       \
+  }
+#define B2_LDX(g) xr[(g) & 3] = *reinterpret_cast<const v4i*>(st + rowx + ck[(g) >> 3] + ((g) & 7) * 16 * B2K);
+      uint2 wraw[4];
+      B2_LDW(0)
+      B2_LDX(0) B2_LDX(1) B2_LDX(2)
+      B2_UNPACK(0)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) wq[i] = *reinterpret_cast<const v4i*>(st + roww + cq0 + i * 32 * (B2K / 2));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) xf[0][j] = *reinterpret_cast<const v4i*>(st + rowx + ck[0] + j * 32 * B2K);
-        B2_UNPACK(0)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const int cb = ks & 1, nb = cb ^ 1;
-          if (ks < 3) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xf[nb][j] = *reinterpret_cast<const v4i*>(st + rowx + ck[ks + 1] + j * 32 * B2K);
-          }
-          if (ks == 1) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) wq[i] = *reinterpret_cast<const v4i*>(st + roww + cq1 + i * 32 * (B2K / 2));
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8((ks & 1) ? wb[ks >> 1][i] : wa[ks >> 1][i], xf[cb][j], acc[i][j], 0, 0, 0);
-          if (ks == 1) { B2_UNPACK(1) }
+      for (int g = 0; g < 16; ++g) {
+        if (g + 3 < 16) { B2_LDX(g + 3) }
+        if (g == 3) { B2_LDW(1) }
+        if (g == 6) { B2_UNPACK(1) }
+        if (W4) {  // six pieces over the first twelve groups (idx 5 and 7 are empty for the packed panel)
+          if (g < 12 && g % 3 != 2 && more_spread) B2_PIECE(kt + 1, (kt + 1) & 1, g - g / 3);
+        } else {
+          if (g < 8 && more_spread) B2_PIECE(kt + 1, (kt + 1) & 1, g);
         }
-#undef B2_UNPACK
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads (and the DMA piece) AHEAD of the MFMAs of group g
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[i][g & 7] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[g >> 3][i], xr[g & 3], acc[i][g & 7], 0, 0, 0);
       }
+#undef B2_UNPACK
+#undef B2_LDW
+#undef B2_LDX
     }
 
     // ---- all waves are done with LDS.  Epilogue, in this order:
@@ -480,27 +489,29 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     float* chan = reinterpret_cast<float*>(smem + B2_STAGE);  // [4][256]: sW, zp*sW, bias, gate
-    float sa_m[4] = {1.f, 1.f, 1.f, 1.f}, asum_m[4] = {0.f, 0.f, 0.f, 0.f};
-    int mrow[4], mcl[4];
+    float sa_m[8], asum_m[8];
+    int mcl[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      mrow[j] = cur_m0 + wm * 128 + j * 32 + fr;
-      mcl[j] = mrow[j] < p.M ? mrow[j] : p.M - 1;
+    for (int j = 0; j < 8; ++j) {
+      sa_m[j] = 1.f;
+      asum_m[j] = 0.f;
+      const int mr = cur_m0 + wm * 128 + j * 16 + r16;
+      mcl[j] = mr < p.M ? mr : p.M - 1;
     }
-    if (OUT != WANQ_I32) {  // one uniform branch per dtype so that the four loads of a kind issue together
+    if (OUT != WANQ_I32) {  // one uniform branch per dtype so that the eight loads of a kind issue together
       if (p.tok_dtype == WANQ_F32) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sa_m[j] = static_cast<const float*>(p.sa)[mcl[j]];
+        for (int j = 0; j < 8; ++j) sa_m[j] = static_cast<const float*>(p.sa)[mcl[j]];
         if (p.zp) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) asum_m[j] = static_cast<const float*>(p.asum)[mcl[j]];
+          for (int j = 0; j < 8; ++j) asum_m[j] = static_cast<const float*>(p.asum)[mcl[j]];
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sa_m[j] = __half2float(static_cast<const __half*>(p.sa)[mcl[j]]);
+        for (int j = 0; j < 8; ++j) sa_m[j] = __half2float(static_cast<const __half*>(p.sa)[mcl[j]]);
         if (p.zp) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) asum_m[j] = __half2float(static_cast<const __half*>(p.asum)[mcl[j]]);
+          for (int j = 0; j < 8; ++j) asum_m[j] = __half2float(static_cast<const __half*>(p.asum)[mcl[j]]);
         }
       }
     }
@@ -536,17 +547,19 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
     asm volatile("" : "+v"(lane_e));
     char* tb = smem + B2_STAGE + 4096 + wave * 4096;
     const int rd_row = lane_e >> 3, rd_c = lane_e & 7;  // read-back: row rd_row + 8*pass, 16-B chunk rd_c
+    const int e16 = lane_e & 15, eq4 = lane_e >> 4;     // = r16, q4 (opaque copies)
     const int tok_base = cur_m0 + wm * 128;
     constexpr bool OUT16 = (OUT == WANQ_F16 || OUT == WANQ_BF16);
     if (OUT16 && !has_res) {
-      // chunk = 32 tokens x 64 channels in the output type
+      // chunk = 32 tokens (token blocks 2J, 2J+1) x 64 channels in the output type
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int J = 0; J < 4; ++J) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = 2 * J + jj, tr = jj * 16 + e16;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int nl = wn * 64 + i * 32 + 8 * g + 4 * fh;
+          for (int i = 0; i < 4; ++i) {
+            const int nl = wn * 64 + i * 16 + 4 * eq4;
             const float4 sw4 = *reinterpret_cast<const float4*>(chan + nl);
             const float4 zs4 = *reinterpret_cast<const float4*>(chan + 256 + nl);
             const float4 b4 = *reinterpret_cast<const float4*>(chan + 512 + nl);
@@ -555,62 +568,66 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
             float y[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e)  // acc*sA*sW + (sumA*(zp*sW) + bias)
-              y[e] = fmaf((float)acc[i][j][4 * g + e] * sa_m[j], swa[e], fmaf(asum_m[j], zsa[e], ba[e]));
+              y[e] = fmaf((float)acc[i][j][e] * sa_m[j], swa[e], fmaf(asum_m[j], zsa[e], ba[e]));
             if (p.epi & WANQ_EPI_GELU) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_fast_f32(y[e]);
             }
-            const int cb = (i * 32 + 8 * g + 4 * fh) * 2;  // byte column inside the 128-B row
-            *reinterpret_cast<uint2*>(tb + fr * 128 + ((((cb >> 4) ^ (fr & 7)) << 4) | (cb & 15))) = pack16x4<OUT>(y);
+            const int cb = (i * 16 + 4 * eq4) * 2;  // byte column inside the 128-B row
+            *reinterpret_cast<uint2*>(tb + tr * 128 + ((((cb >> 4) ^ (tr & 7)) << 4) | (cb & 15))) = pack16x4<OUT>(y);
           }
         }
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
           const int row = rd_row + 8 * ps;
           const uint4 v = *reinterpret_cast<const uint4*>(tb + row * 128 + ((rd_c ^ (row & 7)) << 4));
-          const int tok = tok_base + j * 32 + row;
+          const int tok = tok_base + J * 32 + row;
           const int n = cur_n0 + wn * 64 + rd_c * 8;
           if (full_tile || (tok < p.M && n < p.N))
             *reinterpret_cast<uint4*>(static_cast<uint16_t*>(p.out) + (int64_t)tok * p.N + n) = v;
         }
       }
     } else {
-      // chunk = 32 tokens x 32 channels of fp32 / int32; gate*y + residual is applied after the turn, on whole lines
+      // chunk = 32 tokens x 32 channels (channel blocks 2 ih, 2 ih + 1) of fp32 / int32; gate*y + residual is applied after
+      // the turn, on whole lines
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int J = 0; J < 4; ++J) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int ih = 0; ih < 2; ++ih) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int cb = (8 * g + 4 * fh) * 4;
-            char* dst = tb + fr * 128 + ((((cb >> 4) ^ (fr & 7)) << 4));
-            if (OUT == WANQ_I32) {
-              *reinterpret_cast<int4*>(dst) =
-                  make_int4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-            } else {
-              const int nl = wn * 64 + i * 32 + 8 * g + 4 * fh;
-              const float4 sw4 = *reinterpret_cast<const float4*>(chan + nl);
-              const float4 zs4 = *reinterpret_cast<const float4*>(chan + 256 + nl);
-              const float4 b4 = *reinterpret_cast<const float4*>(chan + 512 + nl);
-              const float swa[4] = {sw4.x, sw4.y, sw4.z, sw4.w}, zsa[4] = {zs4.x, zs4.y, zs4.z, zs4.w};
-              const float ba[4] = {b4.x, b4.y, b4.z, b4.w};
-              float y[4];
+          for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * J + jj, tr = jj * 16 + e16;
 #pragma unroll
-              for (int e = 0; e < 4; ++e)
-                y[e] = fmaf((float)acc[i][j][4 * g + e] * sa_m[j], swa[e], fmaf(asum_m[j], zsa[e], ba[e]));
-              if (p.epi & WANQ_EPI_GELU) {
+            for (int ii = 0; ii < 2; ++ii) {
+              const int i = 2 * ih + ii;
+              char* dst = tb + tr * 128 + (((4 * ii + eq4) ^ (tr & 7)) << 4);
+              if (OUT == WANQ_I32) {
+                *reinterpret_cast<int4*>(dst) = make_int4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+              } else {
+                const int nl = wn * 64 + i * 16 + 4 * eq4;
+                const float4 sw4 = *reinterpret_cast<const float4*>(chan + nl);
+                const float4 zs4 = *reinterpret_cast<const float4*>(chan + 256 + nl);
+                const float4 b4 = *reinterpret_cast<const float4*>(chan + 512 + nl);
+                const float swa[4] = {sw4.x, sw4.y, sw4.z, sw4.w}, zsa[4] = {zs4.x, zs4.y, zs4.z, zs4.w};
+                const float ba[4] = {b4.x, b4.y, b4.z, b4.w};
+                float y[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_fast_f32(y[e]);
+                for (int e = 0; e < 4; ++e)
+                  y[e] = fmaf((float)acc[i][j][e] * sa_m[j], swa[e], fmaf(asum_m[j], zsa[e], ba[e]));
+                if (p.epi & WANQ_EPI_GELU) {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_fast_f32(y[e]);
+                }
+                *reinterpret_cast<float4*>(dst) = make_float4(y[0], y[1], y[2], y[3]);
               }
-              *reinterpret_cast<float4*>(dst) = make_float4(y[0], y[1], y[2], y[3]);
             }
           }
 #pragma unroll
           for (int ps = 0; ps < 4; ++ps) {
             const int row = rd_row + 8 * ps;
             const char* src = tb + row * 128 + ((rd_c ^ (row & 7)) << 4);
-            const int tok = tok_base + j * 32 + row;
-            const int nl = wn * 64 + i * 32 + rd_c * 4;
+            const int tok = tok_base + J * 32 + row;
+            const int nl = wn * 64 + ih * 32 + rd_c * 4;
             const int n = cur_n0 + nl;
             if (!(full_tile || (tok < p.M && n < p.N))) continue;
             const int64_t o = (int64_t)tok * p.N + n;
@@ -634,6 +651,9 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
         }
       }
     }
+#ifdef WANQ_CLOCK_PROBE
+    if (next >= ntiles && blockIdx.x == 77 && tid == 0) { g_gemm_clk[0] = clock64() - clk_c0; g_gemm_clk[1] = wall_clock64() - clk_w0; }
+#endif
     if (next >= ntiles) break;
     // A full tile issues exactly 16 (16-bit output) or 32 store instructions per wave after the LDS-DMA above; a ragged
     // tile may issue fewer (whole-wave skips), so it falls back to a full drain.
@@ -665,6 +685,14 @@ static int launch_gemm(GemmParams p, hipStream_t st) {
     const int tiles = p.mt * p.nt;
     const int grid = tiles < 256 ? ((tiles + 7) & ~7) : 256;  // one workgroup per CU; % 8 == 0 for the XCD ranges
     hipLaunchKernelGGL((gemm_w8a8_big_kernel<OUT, W4>), dim3((unsigned)grid), dim3(512), 2 * B2_STAGE, st, p);
+#ifdef WANQ_CLOCK_PROBE
+    {
+      (void)hipStreamSynchronize(st);
+      unsigned long long h[2];
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm_clk), sizeof(h));
+      printf("[clock] gemm M=%d N=%d K=%d: %llu cycles in %.1f us -> %.0f MHz\n", p.M, p.N, p.K, h[0], h[1] / 100.0, h[0] / (h[1] / 100.0));
+    }
+#endif
   } else {
     hipLaunchKernelGGL((gemm_w8a8_kernel<OUT, W4>), dim3((unsigned)(p.mt * p.nt)), dim3(256), 2 * STAGE_BYTES, st, p);
   }
