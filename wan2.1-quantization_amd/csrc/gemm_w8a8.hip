@@ -551,7 +551,20 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
     const int tok_base = cur_m0 + wm * 128;
     constexpr bool OUT16 = (OUT == WANQ_F16 || OUT == WANQ_BF16);
     if (OUT16 && !has_res) {
-      // chunk = 32 tokens (token blocks 2J, 2J+1) x 64 channels in the output type
+      // chunk = 32 tokens (token blocks 2J, 2J+1) x 64 channels in the output type.  The lane's 16 channels (4 per channel
+      // block i) keep their three per-channel values in registers for the whole loop (48 registers; read per use they were 96
+      // ds_read_b128 per wave and tile).
+      float swa[4][4], zsa[4][4], ba[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int nl = wn * 64 + i * 16 + 4 * eq4;
+        const float4 sw4 = *reinterpret_cast<const float4*>(chan + nl);
+        const float4 zs4 = *reinterpret_cast<const float4*>(chan + 256 + nl);
+        const float4 b4 = *reinterpret_cast<const float4*>(chan + 512 + nl);
+        swa[i][0] = sw4.x; swa[i][1] = sw4.y; swa[i][2] = sw4.z; swa[i][3] = sw4.w;
+        zsa[i][0] = zs4.x; zsa[i][1] = zs4.y; zsa[i][2] = zs4.z; zsa[i][3] = zs4.w;
+        ba[i][0] = b4.x; ba[i][1] = b4.y; ba[i][2] = b4.z; ba[i][3] = b4.w;
+      }
 #pragma unroll
       for (int J = 0; J < 4; ++J) {
 #pragma unroll
@@ -559,16 +572,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
           const int j = 2 * J + jj, tr = jj * 16 + e16;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const int nl = wn * 64 + i * 16 + 4 * eq4;
-            const float4 sw4 = *reinterpret_cast<const float4*>(chan + nl);
-            const float4 zs4 = *reinterpret_cast<const float4*>(chan + 256 + nl);
-            const float4 b4 = *reinterpret_cast<const float4*>(chan + 512 + nl);
-            const float swa[4] = {sw4.x, sw4.y, sw4.z, sw4.w}, zsa[4] = {zs4.x, zs4.y, zs4.z, zs4.w};
-            const float ba[4] = {b4.x, b4.y, b4.z, b4.w};
             float y[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e)  // acc*sA*sW + (sumA*(zp*sW) + bias)
-              y[e] = fmaf((float)acc[i][j][e] * sa_m[j], swa[e], fmaf(asum_m[j], zsa[e], ba[e]));
+              y[e] = fmaf((float)acc[i][j][e] * sa_m[j], swa[i][e], fmaf(asum_m[j], zsa[i][e], ba[i][e]));
             if (p.epi & WANQ_EPI_GELU) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_fast_f32(y[e]);

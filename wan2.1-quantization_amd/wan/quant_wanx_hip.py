@@ -192,23 +192,27 @@ class _LnSrc:
 
 
 class _FpSrc:
-    """An activation that already exists in bf16 (attention output, GELU'd hidden, text context)."""
+    """An activation that already exists in bf16 (attention output, FFN hidden, text context).  `gelu`: the tensor is the FFN's
+    PRE-activation and the quantiser applies the tanh-GELU itself (gelu_quant_sum -- the reference's own split,
+    K/csrc/fused/fused.cu gelu_quant_sum behind a 16-bit GEMM output, W/models/quant_opensora_cuda.py:402); only offered to a
+    consumer that quantises without a rotation."""
 
-    def __init__(self, t, fp_dtype=None):
-        self.t, self.cache, self.fp_dtype = t, {}, fp_dtype
+    def __init__(self, t, fp_dtype=None, gelu=False):
+        self.t, self.cache, self.fp_dtype, self.gelu = t, {}, fp_dtype, gelu
 
     def int8(self, lin):
         key = lin.act_key
         if key not in self.cache:
             qs = torch.empty(2, self.t.shape[0], dtype=torch.float32, device=self.t.device)
             if key is None:
-                q = fused.quant_sum(self.t, qs[1], qs[0])
+                q = (fused.gelu_quant_sum if self.gelu else fused.quant_sum)(self.t, qs[1], qs[0])
             else:
                 q = fused.rotate_quant(self.t, lin.act_premul, lin.rot, qs[1], qs[0])
             self.cache[key] = (q, qs[0], qs[1])
         return self.cache[key]
 
     def fp(self):
+        assert not self.gelu, "a pre-activation source has no floating-point view"
         if self.fp_dtype is not None and self.t.dtype != self.fp_dtype:
             if "fp" not in self.cache:
                 self.cache["fp"] = self.t.to(self.fp_dtype)
@@ -391,8 +395,12 @@ class WanAttentionBlockWithHipKernel(nn.Module):
             o = ops.attention(q, k, v, H)
         self._linear(ca.o, _FpSrc(o), gate=self.ones_gate, residual=x)
 
-        # ---- FFN: LN*(1+e4)+e3 -> GEMM+GELU -> GEMM (+gate, +residual)
+        # ---- FFN: LN*(1+e4)+e3 -> GEMM -> GELU + quantise -> GEMM (+gate, +residual).  The GELU runs in ffn.2's quantiser when
+        # that is a plain per-token quantiser (the memory-bound pass has the vector slack: 439 + 218 us against 494 + 199 us with
+        # the GELU in the GEMM epilogue, whose store loop is vector-bound; cfg-B, tools/probes/ffn_gelu_placement.py); with a
+        # rotation in front of ffn.2, or a floating-point ffn.2, it stays in ffn.0's epilogue.
         h = _LnSrc(self, x, None, e[:, 3], e[:, 4])
-        hid = self._linear(self.ffn0, h, gelu=True)
-        self._linear(self.ffn2, _FpSrc(hid), gate=e[0, 5].contiguous(), residual=x)
+        late_gelu = self.ffn0.quantized and self.ffn2.quantized and self.ffn2.act_key is None
+        hid = self._linear(self.ffn0, h, gelu=not late_gelu)
+        self._linear(self.ffn2, _FpSrc(hid, gelu=late_gelu), gate=e[0, 5].contiguous(), residual=x)
         return x
