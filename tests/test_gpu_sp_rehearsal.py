@@ -60,3 +60,12 @@ def test_bench_multi_rank_control_flow_rehearsal(gpus, plan, extra):
     assert out["roofline"]["frac"] > 0 and "REHEARSAL" in out["data"]
     if extra:  # the flags of BASELINE config 5 (pure Ulysses + sharded packed-W4 / W8 weights), on the 1.3B model
         assert out["config"]["dit_fsdp"]["ranks"] == gpus and "W4A8" in out["config"]["workload"] and "W4A8-mixed" in out["metric"]
+
+
+def test_rccl_backend_single_rank_collective_forms():
+    """torch.distributed backend "nccl" (= RCCL) itself, world size 1 on the one GPU: the call forms, dtypes and async / side-stream
+    semantics of every collective the multi-GPU path issues (rccl_single_rank_worker.py)."""
+    r = subprocess.run([sys.executable, os.path.join(HERE, "rccl_single_rank_worker.py"), str(_free_port())],
+                       env=dict(os.environ, OMP_NUM_THREADS="4"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, f"RCCL single-rank worker failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+    assert "rccl_single_rank ok=7" in r.stdout, r.stdout[-2000:]
