@@ -21,7 +21,9 @@ def t(a):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 8, 16), (7, 24, 48), (128, 128, 128), (130, 136, 144), (257, 384, 1536),
-                                   (1000, 1536, 1536), (333, 8960, 1536), (300, 1536, 8960), (512, 5120, 5120)])
+                                   (1000, 1536, 1536), (333, 8960, 1536), (300, 1536, 8960), (512, 5120, 5120),
+                                   # persistent kernel: one K-tile, two K-tiles (ragged M and N), nk = 32 (LDS-DMA issued at the top)
+                                   (600, 264, 128), (520, 256, 256), (700, 512, 4096)])
 def test_w8a8_o32_bit_exact(M, N, K):
     rng = np.random.default_rng(M * 7 + N + K)
     a = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
