@@ -96,11 +96,25 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
-  const int head = blockIdx.y;
+  // Workgroup -> (head, query block).  The dispatcher hands workgroup L = x + gridDim.x * y to XCD L % 8, so with the plain
+  // (x, y) = (query block, head) reading every XCD works on every head at once and each of the eight L2s streams every K / V
+  // tile (PMC: 1.02 GB per cfg-B launch for 0.30 GB of operands).  The remap gives XCD k the k-th contiguous eighth of the
+  // head-major sequence (bijective for any grid): the 32 workgroups an XCD runs at a time share ONE head, whose K / V tiles
+  // are then fetched by one L2 per pass of 32 query blocks instead of by all eight.
+  int head = blockIdx.y, qblk = blockIdx.x;
+#ifndef WANQ_ATTN_NO_XCD_MAP
+  if (!SPLIT) {
+    const int nqb = gridDim.x, T = nqb * (int)gridDim.y, L = (int)blockIdx.x + nqb * (int)blockIdx.y;
+    const int xq = T >> 3, xr = T & 7, xcd = L & 7;
+    const int i = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (L >> 3);
+    head = i / nqb;
+    qblk = i - head * nqb;
+  }
+#endif
 #ifdef WANQ_CLOCK_PROBE
   const unsigned long long clk_c0 = clock64(), clk_w0 = wall_clock64();
 #endif
-  const int q0 = blockIdx.x * AT_QB + wave * AT_QW;
+  const int q0 = qblk * AT_QB + wave * AT_QW;
   const int nt = (p.Lk + AT_KB - 1) / AT_KB;
   float c = p.c;
   // key tiles of this workgroup: all of them, or one contiguous share under split-KV (the host makes every share non-empty)
