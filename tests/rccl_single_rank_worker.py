@@ -44,6 +44,16 @@ with torch.cuda.stream(side):
 torch.cuda.current_stream().wait_stream(side)
 assert torch.equal(full, w)
 ok += 2
+# ParallelPlan: sub-groups (new_group on a device-bound communicator) and the CFG all-gather in its list form
+grp = dist.new_group([0])
+lst = [torch.empty_like(x) for _ in range(1)]
+dist.all_gather(lst, x.contiguous(), group=grp)
+assert torch.equal(lst[0], x)
+recv = torch.empty(1, 64, 128, device=dev, dtype=torch.bfloat16)
+send = torch.randn(1, 64, 128, device=dev, generator=g).to(torch.bfloat16)
+dist.all_to_all_single(recv, send, group=grp, async_op=True).wait()
+assert torch.equal(recv, send)
+ok += 2
 # bench.py: barrier, max-over-ranks of the step time on the device
 dist.barrier()
 t = torch.tensor([1.25], device=dev, dtype=torch.float64)
