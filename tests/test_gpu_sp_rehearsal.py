@@ -67,5 +67,7 @@ def test_rccl_backend_single_rank_collective_forms():
     semantics of every collective the multi-GPU path issues (rccl_single_rank_worker.py)."""
     r = subprocess.run([sys.executable, os.path.join(HERE, "rccl_single_rank_worker.py"), str(_free_port())],
                        env=dict(os.environ, OMP_NUM_THREADS="4"), capture_output=True, text=True, timeout=300)
+    if r.returncode == 3 and "rccl_init_failed" in r.stdout:
+        pytest.skip("RCCL could not be initialised on this box: " + r.stdout[-500:])
     assert r.returncode == 0, f"RCCL single-rank worker failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
     assert "rccl_single_rank ok=9" in r.stdout, r.stdout[-2000:]
