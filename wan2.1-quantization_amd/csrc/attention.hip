@@ -622,6 +622,278 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
   }
 }
 
+// =====================================================================================================================
+// 16x16x32 form of the bf16 kernel (LDS-DMA ring, no split-KV): the same structure on v_mfma_f32_16x16x32_bf16, whose
+// streams hold a ~10 % higher clock on this part (tools/probes/mfma_shape_clock.hip).  Per wave 32 queries = two blocks
+// nq of 16; per 64-key tile four key blocks kb of 16.
+//   S^T block (kb, nq) = K_kb . Q_nq^T : A = K rows (ds_read_b128: lane (r = lane & 15, g = lane >> 4) reads LDS row
+//       16 kb + kappa(r), 16-B chunk 4 s + g of d-slice s), B = Q fragment in registers.  Accumulator element e of lane
+//       (n, g) is query 16 nq + n against key 16 kb + 4 pi(g) + e, where kappa(4 t + e) = 4 pi(t) + e, pi = (0, 2, 1, 3):
+//       the swap of the two middle row quads makes the transposed V reads below conflict-free.
+//   O^T block (db, nq) += V^T_(db) . P^T_nq : B = two S blocks (2 ks, 2 ks + 1) of the lane converted in place (k index
+//       8 g + j <-> key 32 ks + 16 (j >> 2) + 4 pi(g) + (j & 3)); A = V^T gathered by two ds_read_b64_tr_b16 whose 16-lane
+//       group g reads rows 32 ks + 16 jh + 4 pi(g) + q: the two groups of a 32-lane half sit 8 rows apart (conflict-free).
+//   A query's statistics live in four lanes (n, n + 16, n + 32, n + 48): the running maximum is only reduced across them
+//   when the lazy rescale fires (wave vote on the lane-local maxima); row sums are reduced once, in the epilogue.
+// The K tile's LDS image uses the chunk swizzle row & 15 (conflict-free for this operand's b128 lane groups; the image of
+// the 32x32 kernel is 2-way for them); the V image is the one above.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n16 = lane & 15, g4 = lane >> 4;
+  int head = blockIdx.y, qblk = blockIdx.x;
+  {  // XCD-aware (head, query block) map, as in attn_fwd_kernel
+    const int nqb = gridDim.x, T = nqb * (int)gridDim.y, L = (int)blockIdx.x + nqb * (int)blockIdx.y;
+    const int xq = T >> 3, xr = T & 7, xcd = L & 7;
+    const int i = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (L >> 3);
+    head = i / nqb;
+    qblk = i - head * nqb;
+  }
+  const int q0 = qblk * AT_QB + wave * AT_QW;
+  const int nt = (p.Lk + AT_KB - 1) / AT_KB;
+  const float c = p.c;
+
+  // ---- Q fragments: query q0 + 16 nq + n16, d = 32 s + 8 g4 + [0, 8), pre-scaled by softmax scale * log2(e)
+  bf16x8 qf[2][4];
+#pragma unroll
+  for (int nq = 0; nq < 2; ++nq) {
+    int qr = q0 + 16 * nq + n16;
+    if (qr >= p.Lq) qr = p.Lq - 1;
+    const uint16_t* qp = p.q + (int64_t)qr * p.q_stride + head * AT_D + 8 * g4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[nq][s] = *reinterpret_cast<const bf16x8*>(qp + 32 * s);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[nq][s][e] = (__bf16)((float)qf[nq][s][e] * c);
+  }
+
+  // ---- LDS-DMA: waves 0-3 issue the whole tile, 8 pieces each (rows 16 w + 4 i + d_r of the K tile and of the V tile)
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef __attribute__((address_space(1))) const void glb_void;
+  const bool dma_wave = wave < 4;
+  const int d_r = lane >> 4;
+#define A16_DOFF_V(stride, i) ((uint32_t)((16 * (wave & 3) + 4 * (i) + d_r) * (int)(stride) + head * AT_D + ((((lane & 15) ^ (d_r << 2)) ^ (i)) << 3)) * 2u)
+#define A16_DOFF_K(stride, i) ((uint32_t)((16 * (wave & 3) + 4 * (i) + d_r) * (int)(stride) + head * AT_D + (((lane & 15) ^ (4 * (i) + d_r)) << 3)) * 2u)
+  uint32_t d_k0 = A16_DOFF_K(p.k_stride, 0), d_k1 = A16_DOFF_K(p.k_stride, 1), d_k2 = A16_DOFF_K(p.k_stride, 2), d_k3 = A16_DOFF_K(p.k_stride, 3);
+  uint32_t d_v0 = A16_DOFF_V(p.v_stride, 0), d_v1 = A16_DOFF_V(p.v_stride, 1), d_v2 = A16_DOFF_V(p.v_stride, 2), d_v3 = A16_DOFF_V(p.v_stride, 3);
+#undef A16_DOFF_V
+#undef A16_DOFF_K
+#define A16_DMA_F(base, off, tilebyte, i) \
+  __builtin_amdgcn_global_load_lds((glb_void*)((base) + (off)), (lds_void*)(sK_ + (tilebyte) + 1024 * (i)), 16, 0, 0);
+#define A16_DMA_S(base, stride, tilebyte, i, j, kswz)                                                           \
+  {                                                                                                             \
+    int kr_ = (j) * AT_KB + 16 * (wave & 3) + 4 * (i) + d_r;                                                    \
+    kr_ = kr_ < p.Lk ? kr_ : p.Lk - 1;                                                                          \
+    const int col_ = head * AT_D + ((kswz ? ((lane & 15) ^ (4 * (i) + d_r)) : (((lane & 15) ^ (d_r << 2)) ^ (i))) << 3); \
+    __builtin_amdgcn_global_load_lds((glb_void*)((base) + (int64_t)kr_ * (stride) + col_), (lds_void*)(sK_ + (tilebyte) + 1024 * (i)), 16, 0, 0); \
+  }
+#define A16_DMA(j, stage)                                                                                       \
+  do {                                                                                                          \
+    if (dma_wave) {                                                                                             \
+      char* sK_ = smem + (stage) * AT_STAGE + (wave & 3) * 4096;                                                \
+      if (((j) + 1) * AT_KB <= p.Lk) {                                                                          \
+        const char* kt_ = reinterpret_cast<const char*>(p.k) + (int64_t)(j) * (AT_KB * 2) * p.k_stride;         \
+        const char* vt_ = reinterpret_cast<const char*>(p.v) + (int64_t)(j) * (AT_KB * 2) * p.v_stride;         \
+        A16_DMA_F(kt_, d_k0, 0, 0) A16_DMA_F(kt_, d_k1, 0, 1) A16_DMA_F(kt_, d_k2, 0, 2) A16_DMA_F(kt_, d_k3, 0, 3) \
+        A16_DMA_F(vt_, d_v0, AT_TILE, 0) A16_DMA_F(vt_, d_v1, AT_TILE, 1) A16_DMA_F(vt_, d_v2, AT_TILE, 2) A16_DMA_F(vt_, d_v3, AT_TILE, 3) \
+      } else {                                                                                                  \
+        A16_DMA_S(p.k, p.k_stride, 0, 0, j, true) A16_DMA_S(p.k, p.k_stride, 0, 1, j, true) A16_DMA_S(p.k, p.k_stride, 0, 2, j, true) A16_DMA_S(p.k, p.k_stride, 0, 3, j, true) \
+        A16_DMA_S(p.v, p.v_stride, AT_TILE, 0, j, false) A16_DMA_S(p.v, p.v_stride, AT_TILE, 1, j, false) A16_DMA_S(p.v, p.v_stride, AT_TILE, 2, j, false) A16_DMA_S(p.v, p.v_stride, AT_TILE, 3, j, false) \
+      }                                                                                                         \
+    }                                                                                                           \
+  } while (0)
+
+  // ---- fragment read offsets
+  const int kap = 4 * (2 * ((n16 >> 2) & 1) + ((n16 >> 3) & 1)) + (n16 & 3);  // kappa(n16)
+  uint32_t koff0 = kap * 256 + (((0 + g4) ^ kap) << 4), koff1 = kap * 256 + (((4 + g4) ^ kap) << 4);
+  uint32_t koff2 = kap * 256 + (((8 + g4) ^ kap) << 4), koff3 = kap * 256 + (((12 + g4) ^ kap) << 4);
+  const int pg = 2 * (g4 & 1) + (g4 >> 1), tq = (lane >> 2) & 3, tp = lane & 3;
+  const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+#define A16_VA(db) (uint32_t)(at_off(4 * pg + tq, 2 * (db) + (tp >> 1)) + 8 * (tp & 1))
+  const uint32_t va0 = A16_VA(0), va1 = A16_VA(1), va2 = A16_VA(2), va3 = A16_VA(3);
+  const uint32_t va4 = A16_VA(4), va5 = A16_VA(5), va6 = A16_VA(6), va7 = A16_VA(7);
+#undef A16_VA
+
+  f32x4 o[8][2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[i][nq][r] = 0.f;
+  float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+  f32x4 sinit[2];
+#pragma unroll
+  for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sinit[nq][r] = 0.f;
+
+  A16_DMA(0, 0);
+  if (1 < nt) {
+    A16_DMA(1, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+
+  for (int j0 = 0; j0 < nt; j0 += 3) {
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int j = j0 + u;
+    if (j >= nt) break;
+    const char* sK = smem + u * AT_STAGE;
+    asm volatile("" : "+v"(d_k0), "+v"(d_k1), "+v"(d_k2), "+v"(d_k3), "+v"(d_v0), "+v"(d_v1), "+v"(d_v2), "+v"(d_v3));
+    if (j + 2 < nt) A16_DMA(j + 2, (u + 2) % 3);
+
+    // ---------------- S^T blocks: fragment i = 4 kb + s read four ahead of its two MFMAs
+    f32x4 sacc[4][2];
+    bf16x8 kf[16];
+#define A16_KF(i) kf[i] = *reinterpret_cast<const bf16x8*>(sK + (((i) & 3) == 0 ? koff0 : ((i) & 3) == 1 ? koff1 : ((i) & 3) == 2 ? koff2 : koff3) + ((i) >> 2) * 4096)
+    A16_KF(0); A16_KF(1); A16_KF(2); A16_KF(3);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (i + 4 < 16) { A16_KF(i + 4); }
+      __builtin_amdgcn_sched_barrier(0);
+      const int kb = i >> 2, s = i & 3;
+      sacc[kb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i], qf[0][s], s == 0 ? sinit[0] : sacc[kb][0], 0, 0, 0);
+      sacc[kb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i], qf[1][s], s == 0 ? sinit[1] : sacc[kb][1], 0, 0, 0);
+    }
+#undef A16_KF
+    if (j == nt - 1 && (p.Lk & (AT_KB - 1))) {  // ragged last tile: keys >= Lk get -inf
+      asm volatile("" ::: "memory");
+      const int kbase = j * AT_KB + 4 * pg;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (kbase + 16 * kb + e >= p.Lk) { sacc[kb][0][e] = -INFINITY; sacc[kb][1][e] = -INFINITY; }
+    }
+
+    // ---------------- online softmax: lane-local maxima, cross-lane only when the reference moves
+    float mx0 = sacc[0][0][0], mx1 = sacc[0][1][0];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { mx0 = fmaxf(mx0, sacc[kb][0][e]); mx1 = fmaxf(mx1, sacc[kb][1][e]); }
+    const bool first = (j == 0);
+    if (first || __any(fmaxf(mx0, mx1) > 6.0f)) {
+      asm volatile("" ::: "memory");  // keep this a branch
+      float mx[2] = {mx0, mx1};
+#pragma unroll
+      for (int nq = 0; nq < 2; ++nq) {
+        float m = mx[nq];
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float delta = first ? m : fmaxf(m, 0.f);
+        if (!first) {
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+          l_run[nq] *= alpha;
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[i][nq][r] *= alpha;
+        }
+        m_run[nq] = first ? delta : m_run[nq] + delta;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sacc[kb][nq][e] -= delta;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sinit[nq][r] = -m_run[nq];
+      }
+    }
+    // P of key slice ks (32 keys) for query block nq: element j = 4 (kb & 1) + e of S block kb = 2 ks + (j >> 2)
+    float ls0 = 0.f, ls1 = 0.f;
+    bf16x8 pf[2][2];
+#define A16_EXP(kb, nq, e)                                                     \
+  {                                                                            \
+    const float x_ = __builtin_amdgcn_exp2f(sacc[kb][nq][e]);                  \
+    if (nq == 0) { ls0 += x_; asm volatile("" : "+v"(ls0)); }                  \
+    else { ls1 += x_; asm volatile("" : "+v"(ls1)); }                          \
+    pf[(kb) >> 1][nq][4 * ((kb) & 1) + (e)] = (__bf16)x_;                      \
+  }
+#define A16_EXP4(kb, nq) A16_EXP(kb, nq, 0) A16_EXP(kb, nq, 1) A16_EXP(kb, nq, 2) A16_EXP(kb, nq, 3)
+
+    // ---------------- O^T += V^T . P^T
+    const uint32_t vb = lds_base + u * AT_STAGE;
+    s16x4 ta0, ta1, ta2, ta3, ta4, ta5, ta6, ta7, tb0, tb1, tb2, tb3, tb4, tb5, tb6, tb7;
+#define A16_TR(dst, areg, ks, jh) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(vb + areg), "n"(AT_TILE + 8192 * (ks) + 4096 * (jh)))
+#define A16_TR8(P, ks, a0_, a1_, a2_, a3_)                                                                      \
+  A16_TR(P##0, a0_, ks, 0); A16_TR(P##1, a0_, ks, 1); A16_TR(P##2, a1_, ks, 0); A16_TR(P##3, a1_, ks, 1);     \
+  A16_TR(P##4, a2_, ks, 0); A16_TR(P##5, a2_, ks, 1); A16_TR(P##6, a3_, ks, 0); A16_TR(P##7, a3_, ks, 1)
+#define A16_WAIT8(P, n)                                                                                    \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(P##0), "+v"(P##1), "+v"(P##2), "+v"(P##3), "+v"(P##4), "+v"(P##5), "+v"(P##6), "+v"(P##7))
+#define A16_PV(P, a, b, ks, db, nq) o[db][nq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_join(P##a, P##b), pf[ks][nq], o[db][nq], 0, 0, 0)
+#define A16_F() __builtin_amdgcn_sched_barrier(0)
+    A16_TR8(ta, 0, va0, va1, va2, va3);
+    A16_TR8(tb, 0, va4, va5, va6, va7);
+    A16_EXP4(0, 0) A16_EXP4(1, 0) A16_EXP4(0, 1) A16_EXP4(1, 1)
+    A16_F();
+    A16_WAIT8(ta, 8);
+    // slice 0, d blocks 0-3: one exponential of slice 1 behind every MFMA
+    A16_PV(ta, 0, 1, 0, 0, 0); A16_F(); A16_EXP(2, 0, 0) A16_F(); A16_PV(ta, 0, 1, 0, 0, 1); A16_F(); A16_EXP(2, 0, 1) A16_F();
+    A16_PV(ta, 2, 3, 0, 1, 0); A16_F(); A16_EXP(2, 0, 2) A16_F(); A16_PV(ta, 2, 3, 0, 1, 1); A16_F(); A16_EXP(2, 0, 3) A16_F();
+    A16_PV(ta, 4, 5, 0, 2, 0); A16_F(); A16_EXP(3, 0, 0) A16_F(); A16_PV(ta, 4, 5, 0, 2, 1); A16_F(); A16_EXP(3, 0, 1) A16_F();
+    A16_PV(ta, 6, 7, 0, 3, 0); A16_F(); A16_EXP(3, 0, 2) A16_F(); A16_PV(ta, 6, 7, 0, 3, 1); A16_F(); A16_EXP(3, 0, 3) A16_F();
+    A16_TR8(ta, 1, va0, va1, va2, va3);
+    A16_WAIT8(tb, 8);
+    A16_PV(tb, 0, 1, 0, 4, 0); A16_F(); A16_EXP(2, 1, 0) A16_F(); A16_PV(tb, 0, 1, 0, 4, 1); A16_F(); A16_EXP(2, 1, 1) A16_F();
+    A16_PV(tb, 2, 3, 0, 5, 0); A16_F(); A16_EXP(2, 1, 2) A16_F(); A16_PV(tb, 2, 3, 0, 5, 1); A16_F(); A16_EXP(2, 1, 3) A16_F();
+    A16_PV(tb, 4, 5, 0, 6, 0); A16_F(); A16_EXP(3, 1, 0) A16_F(); A16_PV(tb, 4, 5, 0, 6, 1); A16_F(); A16_EXP(3, 1, 1) A16_F();
+    A16_PV(tb, 6, 7, 0, 7, 0); A16_F(); A16_EXP(3, 1, 2) A16_F(); A16_PV(tb, 6, 7, 0, 7, 1); A16_F(); A16_EXP(3, 1, 3) A16_F();
+    A16_TR8(tb, 1, va4, va5, va6, va7);
+    A16_WAIT8(ta, 8);
+    A16_PV(ta, 0, 1, 1, 0, 0); A16_PV(ta, 0, 1, 1, 0, 1); A16_PV(ta, 2, 3, 1, 1, 0); A16_PV(ta, 2, 3, 1, 1, 1);
+    A16_PV(ta, 4, 5, 1, 2, 0); A16_PV(ta, 4, 5, 1, 2, 1); A16_PV(ta, 6, 7, 1, 3, 0); A16_PV(ta, 6, 7, 1, 3, 1);
+    A16_WAIT8(tb, 0);
+    A16_PV(tb, 0, 1, 1, 4, 0); A16_PV(tb, 0, 1, 1, 4, 1); A16_PV(tb, 2, 3, 1, 5, 0); A16_PV(tb, 2, 3, 1, 5, 1);
+    A16_PV(tb, 4, 5, 1, 6, 0); A16_PV(tb, 4, 5, 1, 6, 1); A16_PV(tb, 6, 7, 1, 7, 0); A16_PV(tb, 6, 7, 1, 7, 1);
+    l_run[0] += ls0;
+    l_run[1] += ls1;
+#undef A16_EXP
+#undef A16_EXP4
+#undef A16_TR
+#undef A16_TR8
+#undef A16_WAIT8
+#undef A16_PV
+#undef A16_F
+    // tile j+1 must have landed; the eight instructions of tile j+2 (if issued; waves 4-7 issue none) may stay in flight
+    if (j + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  }
+#undef A16_DMA
+#undef A16_DMA_F
+#undef A16_DMA_S
+
+  // ---- epilogue: O[q, d] = O^T[d, q] / l ; lane holds d = 16 db + 4 g4 + e of query 16 nq + n16
+#pragma unroll
+  for (int nq = 0; nq < 2; ++nq) {
+    float l = l_run[nq];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const int qr = q0 + 16 * nq + n16;
+    if (qr < p.Lq) {
+      uint16_t* op = p.o + (int64_t)qr * p.o_stride + head * AT_D + 4 * g4;
+#pragma unroll
+      for (int db = 0; db < 8; ++db) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x4 b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = (__bf16)(o[db][nq][e] * inv);
+        *reinterpret_cast<bf16x4*>(op + 16 * db) = b;
+      }
+    }
+  }
+}
+
 // Split-KV merge: out[q, h, :] = sum_z w_z O_z / sum_z w_z l_z,  w_z = 2^{(m_z - max_z m_z) c}.  One thread per 4 channels.
 __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnParams p, int splits) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -725,7 +997,21 @@ static int attention_impl(const void* q, const void* k, const void* v, void* o, 
       (void)attr_v1;
       hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(512), 2 * AT_STAGE, st, p);
     } else {
-      launch_attn<false, false>(p, grid, st);
+      // WANQ_ATTN_M16=1 selects the 16x16x32 form of the kernel (measured); default: the 32x32x16 form
+#ifndef WANQ_ATTN_M16_DEFAULT
+#define WANQ_ATTN_M16_DEFAULT 1
+#endif
+      static const bool m16 = [] { const char* e = getenv("WANQ_ATTN_M16"); return e ? e[0] == '1' : (WANQ_ATTN_M16_DEFAULT != 0); }();
+      if (m16) {
+        static const bool attr16 = [] {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * AT_STAGE);
+          return true;
+        }();
+        (void)attr16;
+        hipLaunchKernelGGL(attn_fwd16_kernel, grid, dim3(512), 3 * AT_STAGE, st, p);
+      } else {
+        launch_attn<false, false>(p, grid, st);
+      }
     }
 #ifdef WANQ_CLOCK_PROBE
     {
