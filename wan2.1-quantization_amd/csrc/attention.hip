@@ -639,12 +639,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
 // the 32x32 kernel is 2-way for them); the V image is the one above.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+template <bool SPLIT>
 __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n16 = lane & 15, g4 = lane >> 4;
   int head = blockIdx.y, qblk = blockIdx.x;
-  {  // XCD-aware (head, query block) map, as in attn_fwd_kernel
+  if (!SPLIT) {  // XCD-aware (head, query block) map, as in attn_fwd_kernel
     const int nqb = gridDim.x, T = nqb * (int)gridDim.y, L = (int)blockIdx.x + nqb * (int)blockIdx.y;
     const int xq = T >> 3, xr = T & 7, xcd = L & 7;
     const int i = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (L >> 3);
@@ -653,6 +654,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
   }
   const int q0 = qblk * AT_QB + wave * AT_QW;
   const int nt = (p.Lk + AT_KB - 1) / AT_KB;
+  // key tiles of this workgroup: all of them, or one contiguous share under split-KV (the host makes every share non-empty)
+  const int jt0 = SPLIT ? (int)blockIdx.z * p.tiles_per_split : 0;
+  const int jt1 = SPLIT ? (jt0 + p.tiles_per_split < nt ? jt0 + p.tiles_per_split : nt) : nt;
   const float c = p.c;
 
   // ---- Q fragments: query q0 + 16 nq + n16, d = 32 s + 8 g4 + [0, 8), pre-scaled by softmax scale * log2(e)
@@ -731,9 +735,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
 #pragma unroll
     for (int r = 0; r < 4; ++r) sinit[nq][r] = 0.f;
 
-  A16_DMA(0, 0);
-  if (1 < nt) {
-    A16_DMA(1, 1);
+  A16_DMA(jt0, 0);
+  if (jt0 + 1 < jt1) {
+    A16_DMA(jt0 + 1, 1);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -741,14 +745,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
   __builtin_amdgcn_s_barrier();
   if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
 
-  for (int j0 = 0; j0 < nt; j0 += 3) {
+  for (int j0 = jt0; j0 < jt1; j0 += 3) {
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
     const int j = j0 + u;
-    if (j >= nt) break;
+    if (j >= jt1) break;
     const char* sK = smem + u * AT_STAGE;
     asm volatile("" : "+v"(d_k0), "+v"(d_k1), "+v"(d_k2), "+v"(d_k3), "+v"(d_v0), "+v"(d_v1), "+v"(d_v2), "+v"(d_v3));
-    if (j + 2 < nt) A16_DMA(j + 2, (u + 2) % 3);
+    if (j + 2 < jt1) A16_DMA(j + 2, (u + 2) % 3);
 
     // ---------------- S^T blocks: fragment i = 4 kb + s read four ahead of its two MFMAs
     f32x4 sacc[4][2];
@@ -780,7 +784,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
       for (int e = 0; e < 4; ++e) { mx0 = fmaxf(mx0, sacc[kb][0][e]); mx1 = fmaxf(mx1, sacc[kb][1][e]); }
-    const bool first = (j == 0);
+    const bool first = (j == jt0);
     if (first || __any(fmaxf(mx0, mx1) > 6.0f)) {
       asm volatile("" ::: "memory");  // keep this a branch
       float mx[2] = {mx0, mx1};
@@ -863,7 +867,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
 #undef A16_PV
 #undef A16_F
     // tile j+1 must have landed; the eight instructions of tile j+2 (if issued; waves 4-7 issue none) may stay in flight
-    if (j + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (j + 2 < jt1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
@@ -878,6 +882,21 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
     float l = l_run[nq];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
+    if (SPLIT) {  // unnormalised partials; attn_combine_kernel merges the splits
+      const int qs = q0 + 16 * nq + n16;
+      if (qs < p.Lq) {
+        float* po = p.part_o + ((int64_t)blockIdx.z * p.Lq + qs) * (p.H * AT_D) + head * AT_D + 4 * g4;
+#pragma unroll
+        for (int db = 0; db < 8; ++db)
+          *reinterpret_cast<float4*>(po + 16 * db) = make_float4(o[db][nq][0], o[db][nq][1], o[db][nq][2], o[db][nq][3]);
+        if (g4 == 0) {
+          float* pm = p.part_ml + (((int64_t)blockIdx.z * p.Lq + qs) * p.H + head) * 2;
+          pm[0] = m_run[nq] / p.c;  // the merge kernel computes exp2((m - M) * p.c): m in raw-score units
+          pm[1] = l;
+        }
+      }
+      continue;
+    }
     const float inv = 1.0f / l;
     const int qr = q0 + 16 * nq + n16;
     if (qr < p.Lq) {
@@ -944,6 +963,21 @@ static void launch_attn(const AttnParams& p, dim3 grid, hipStream_t st) {
   hipLaunchKernelGGL((attn_fwd_kernel<true, SPLIT, QK8>), grid, dim3(512), lds, st, p);
 }
 
+// The bf16 kernel exists in two MFMA shapes: 16x16x32 (default: the part holds a higher clock under it and the softmax's
+// exponentials fit one per MFMA; +5 % at cfg-B in one process, +3.4 % inside the step) and 32x32x16 (WANQ_ATTN_M16=0).
+#ifndef WANQ_ATTN_M16_DEFAULT
+#define WANQ_ATTN_M16_DEFAULT 1
+#endif
+static bool use_m16() {
+  static const bool m16 = [] {
+    const char* e = getenv("WANQ_ATTN_M16");
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * AT_STAGE);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * AT_STAGE);
+    return e ? e[0] == '1' : (WANQ_ATTN_M16_DEFAULT != 0);
+  }();
+  return m16;
+}
+
 static int attention_impl(const void* q, const void* k, const void* v, void* o, int dtype, int64_t Lq, int64_t Lk, int heads,
                           int head_dim, int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride, float scale,
                           int splits, void* workspace, int64_t workspace_bytes, void* stream, const Qk8Args* q8 = nullptr) {
@@ -996,22 +1030,10 @@ static int attention_impl(const void* q, const void* k, const void* v, void* o, 
       }();
       (void)attr_v1;
       hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(512), 2 * AT_STAGE, st, p);
+    } else if (use_m16()) {
+      hipLaunchKernelGGL(attn_fwd16_kernel<false>, grid, dim3(512), 3 * AT_STAGE, st, p);
     } else {
-      // WANQ_ATTN_M16=1 selects the 16x16x32 form of the kernel (measured); default: the 32x32x16 form
-#ifndef WANQ_ATTN_M16_DEFAULT
-#define WANQ_ATTN_M16_DEFAULT 1
-#endif
-      static const bool m16 = [] { const char* e = getenv("WANQ_ATTN_M16"); return e ? e[0] == '1' : (WANQ_ATTN_M16_DEFAULT != 0); }();
-      if (m16) {
-        static const bool attr16 = [] {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * AT_STAGE);
-          return true;
-        }();
-        (void)attr16;
-        hipLaunchKernelGGL(attn_fwd16_kernel, grid, dim3(512), 3 * AT_STAGE, st, p);
-      } else {
-        launch_attn<false, false>(p, grid, st);
-      }
+      launch_attn<false, false>(p, grid, st);
     }
 #ifdef WANQ_CLOCK_PROBE
     {
@@ -1042,6 +1064,7 @@ static int attention_impl(const void* q, const void* k, const void* v, void* o, 
   p.part_ml = p.part_o + (int64_t)splits * Lq * heads * AT_D;
   grid.z = (unsigned)splits;
   if (q8) launch_attn<true, true>(p, grid, st);
+  else if (use_m16()) hipLaunchKernelGGL(attn_fwd16_kernel<true>, grid, dim3(512), 3 * AT_STAGE, st, p);
   else launch_attn<true, false>(p, grid, st);
   const int64_t threads = Lq * heads * (AT_D / 4);
   hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p, splits);
