@@ -351,7 +351,7 @@ def main():
     asum = atimer.summary()
     if asum:
         ach = asum["ops"] / asum["seconds"]
-        lines.append({"bound": "mfma", "kernel": "attn_fwd_kernel (bf16 MFMA flash attention, self + cross)" if attn_desc == "bf16" else f"attn_fwd_kernel ({attn_desc})", "achieved": ach / 1e12,
+        lines.append({"bound": "mfma", "kernel": "attn_fwd16_kernel (bf16 MFMA 16x16x32 flash attention, self + cross; WANQ_ATTN_M16=0: attn_fwd_kernel, 32x32x16)" if attn_desc == "bf16" else f"attn_fwd_kernel ({attn_desc})", "achieved": ach / 1e12,
                       "peak": BF16_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK,
                       "traffic": a_traffic, "traffic_source": a_src, "traffic_unit": "HBM bytes per launch (PMC)",
                       "launches": asum["launches"], "avg_launch_us": asum["seconds"] / asum["launches"] * 1e6,
