@@ -639,8 +639,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
 // the 32x32 kernel is 2-way for them); the V image is the one above.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <bool SPLIT>
+template <bool SPLIT, bool QK8>
 __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) {
+  constexpr int STAGE = QK8 ? AT_STAGE8 : AT_STAGE;
+  constexpr int VOFF = QK8 ? AT_K8 : AT_TILE;  // byte offset of the V tile inside a stage
+  typedef int v4i __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n16 = lane & 15, g4 = lane >> 4;
@@ -660,18 +663,28 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
   const float c = p.c;
 
   // ---- Q fragments: query q0 + 16 nq + n16, d = 32 s + 8 g4 + [0, 8), pre-scaled by softmax scale * log2(e)
-  bf16x8 qf[2][4];
+  // QK8: int8 codes, d = 64 s + 16 g4 + [0, 16); the query's scale delta_q rides in the exp2 coefficient c2[nq]
+  bf16x8 qf[QK8 ? 1 : 2][QK8 ? 1 : 4];
+  v4i qf8[QK8 ? 2 : 1][QK8 ? 2 : 1];
+  float c2[2] = {c, c};
 #pragma unroll
   for (int nq = 0; nq < 2; ++nq) {
     int qr = q0 + 16 * nq + n16;
     if (qr >= p.Lq) qr = p.Lq - 1;
-    const uint16_t* qp = p.q + (int64_t)qr * p.q_stride + head * AT_D + 8 * g4;
+    if (QK8) {
+      const int8_t* qp8 = p.q8 + (int64_t)qr * p.q8_stride + head * AT_D + 16 * g4;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[nq][s] = *reinterpret_cast<const bf16x8*>(qp + 32 * s);
+      for (int s = 0; s < 2; ++s) qf8[QK8 ? nq : 0][QK8 ? s : 0] = *reinterpret_cast<const v4i*>(qp8 + 64 * s);
+      c2[nq] = c * p.q_scale[(int64_t)head * p.qs_stride + qr];  // score = dot * delta_k * delta_q * softmax scale
+    } else {
+      const uint16_t* qp = p.q + (int64_t)qr * p.q_stride + head * AT_D + 8 * g4;
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s) qf[QK8 ? 0 : nq][QK8 ? 0 : s] = *reinterpret_cast<const bf16x8*>(qp + 32 * s);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) qf[nq][s][e] = (__bf16)((float)qf[nq][s][e] * c);
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[QK8 ? 0 : nq][QK8 ? 0 : s][e] = (__bf16)((float)qf[QK8 ? 0 : nq][QK8 ? 0 : s][e] * c);
+    }
   }
 
   // ---- LDS-DMA: waves 0-3 issue the whole tile, 8 pieces each (rows 16 w + 4 i + d_r of the K tile and of the V tile)
@@ -681,7 +694,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
   const int d_r = lane >> 4;
 #define A16_DOFF_V(stride, i) ((uint32_t)((16 * (wave & 3) + 4 * (i) + d_r) * (int)(stride) + head * AT_D + ((((lane & 15) ^ (d_r << 2)) ^ (i)) << 3)) * 2u)
 #define A16_DOFF_K(stride, i) ((uint32_t)((16 * (wave & 3) + 4 * (i) + d_r) * (int)(stride) + head * AT_D + (((lane & 15) ^ (4 * (i) + d_r)) << 3)) * 2u)
-  uint32_t d_k0 = A16_DOFF_K(p.k_stride, 0), d_k1 = A16_DOFF_K(p.k_stride, 1), d_k2 = A16_DOFF_K(p.k_stride, 2), d_k3 = A16_DOFF_K(p.k_stride, 3);
+  uint32_t d_k0 = QK8 ? 0u : A16_DOFF_K(p.k_stride, 0), d_k1 = QK8 ? 0u : A16_DOFF_K(p.k_stride, 1), d_k2 = QK8 ? 0u : A16_DOFF_K(p.k_stride, 2),
+           d_k3 = QK8 ? 0u : A16_DOFF_K(p.k_stride, 3);
+  // QK8: the K tile is int8 (8 rows x 128 B per 1-KiB piece, 2 pieces per DMA wave: rows 16 w + 8 i + (lane >> 3), physical chunk
+  // lane & 7 holds logical chunk (lane & 7) ^ ((row >> 1) & 7)); waves 4 and 5 fetch the tile's 64 key scales / constants
+  const int d8_r = lane >> 3;
+#define A16_D8OFF(i) ((uint32_t)((16 * (wave & 3) + 8 * (i) + d8_r) * (int)p.k8_stride + head * AT_D + ((((lane & 7) ^ (((8 * (i) + d8_r) >> 1) & 7))) << 4)))
+  const uint32_t d8_k0 = QK8 ? A16_D8OFF(0) : 0u, d8_k1 = QK8 ? A16_D8OFF(1) : 0u;
+#undef A16_D8OFF
   uint32_t d_v0 = A16_DOFF_V(p.v_stride, 0), d_v1 = A16_DOFF_V(p.v_stride, 1), d_v2 = A16_DOFF_V(p.v_stride, 2), d_v3 = A16_DOFF_V(p.v_stride, 3);
 #undef A16_DOFF_V
 #undef A16_DOFF_K
@@ -694,8 +714,35 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
     const int col_ = head * AT_D + ((kswz ? ((lane & 15) ^ (4 * (i) + d_r)) : (((lane & 15) ^ (d_r << 2)) ^ (i))) << 3); \
     __builtin_amdgcn_global_load_lds((glb_void*)((base) + (int64_t)kr_ * (stride) + col_), (lds_void*)(sK_ + (tilebyte) + 1024 * (i)), 16, 0, 0); \
   }
+#define A16_DMA8(j, stage)                                                                                      \
+  do {                                                                                                          \
+    char* st_ = smem + (stage) * STAGE;                                                                         \
+    if (dma_wave) {                                                                                             \
+      char* sK8_ = st_ + (wave & 3) * 2048;                                                                     \
+      char* sK_ = st_ + (wave & 3) * 4096;                                                                      \
+      if (((j) + 1) * AT_KB <= p.Lk) {                                                                          \
+        const char* kt_ = reinterpret_cast<const char*>(p.k8) + (int64_t)(j) * AT_KB * p.k8_stride;             \
+        const char* vt_ = reinterpret_cast<const char*>(p.v) + (int64_t)(j) * (AT_KB * 2) * p.v_stride;         \
+        __builtin_amdgcn_global_load_lds((glb_void*)(kt_ + d8_k0), (lds_void*)(sK8_), 16, 0, 0);                \
+        __builtin_amdgcn_global_load_lds((glb_void*)(kt_ + d8_k1), (lds_void*)(sK8_ + 1024), 16, 0, 0);         \
+        A16_DMA_F(vt_, d_v0, AT_K8, 0) A16_DMA_F(vt_, d_v1, AT_K8, 1) A16_DMA_F(vt_, d_v2, AT_K8, 2) A16_DMA_F(vt_, d_v3, AT_K8, 3) \
+      } else {                                                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                      \
+          int kr_ = (j) * AT_KB + 16 * (wave & 3) + 8 * i_ + d8_r;                                              \
+          kr_ = kr_ < p.Lk ? kr_ : p.Lk - 1;                                                                    \
+          const int col_ = head * AT_D + ((((lane & 7) ^ (((8 * i_ + d8_r) >> 1) & 7))) << 4);                  \
+          __builtin_amdgcn_global_load_lds((glb_void*)(p.k8 + (int64_t)kr_ * p.k8_stride + col_), (lds_void*)(sK8_ + 1024 * i_), 16, 0, 0); \
+        }                                                                                                       \
+        A16_DMA_S(p.v, p.v_stride, AT_K8, 0, j, false) A16_DMA_S(p.v, p.v_stride, AT_K8, 1, j, false) A16_DMA_S(p.v, p.v_stride, AT_K8, 2, j, false) A16_DMA_S(p.v, p.v_stride, AT_K8, 3, j, false) \
+      }                                                                                                         \
+    } else if (wave < 6) { /* scale plane (wave 4) / constant plane (wave 5): 64 floats, one dword per lane */  \
+      const float* sp_ = p.k_scale + (int64_t)(wave - 4) * p.H * p.ks_stride + (int64_t)head * p.ks_stride + (int64_t)(j) * AT_KB + lane; \
+      __builtin_amdgcn_global_load_lds((glb_void*)sp_, (lds_void*)(st_ + AT_SC8 + (wave - 4) * 256), 4, 0, 0);  \
+    }                                                                                                           \
+  } while (0)
 #define A16_DMA(j, stage)                                                                                       \
   do {                                                                                                          \
+    if (QK8) { A16_DMA8(j, stage); break; }                                                                     \
     if (dma_wave) {                                                                                             \
       char* sK_ = smem + (stage) * AT_STAGE + (wave & 3) * 4096;                                                \
       if (((j) + 1) * AT_KB <= p.Lk) {                                                                          \
@@ -714,6 +761,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
   const int kap = 4 * (2 * ((n16 >> 2) & 1) + ((n16 >> 3) & 1)) + (n16 & 3);  // kappa(n16)
   uint32_t koff0 = kap * 256 + (((0 + g4) ^ kap) << 4), koff1 = kap * 256 + (((4 + g4) ^ kap) << 4);
   uint32_t koff2 = kap * 256 + (((8 + g4) ^ kap) << 4), koff3 = kap * 256 + (((12 + g4) ^ kap) << 4);
+  // QK8: 128-B rows, chunk swizzle (row >> 1) & 7 (at_off8): row 16 kb + kappa, chunk 4 s + g4
+  const uint32_t k8off0 = kap * 128 + (((0 + g4) ^ ((kap >> 1) & 7)) << 4), k8off1 = kap * 128 + (((4 + g4) ^ ((kap >> 1) & 7)) << 4);
   const int pg = 2 * (g4 & 1) + (g4 >> 1), tq = (lane >> 2) & 3, tp = lane & 3;
   const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
 #define A16_VA(db) (uint32_t)(at_off(4 * pg + tq, 2 * (db) + (tp >> 1)) + 8 * (tp & 1))
@@ -728,17 +777,25 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
     for (int nq = 0; nq < 2; ++nq)
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[i][nq][r] = 0.f;
-  float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+  float m_run[2] = {QK8 ? -INFINITY : 0.f, QK8 ? -INFINITY : 0.f}, l_run[2] = {0.f, 0.f};
   f32x4 sinit[2];
 #pragma unroll
   for (int nq = 0; nq < 2; ++nq)
 #pragma unroll
     for (int r = 0; r < 4; ++r) sinit[nq][r] = 0.f;
 
+  // LDS-DMA instructions a wave issues per tile (= what may stay in flight behind a counted wait): 8 for the DMA waves of the
+  // bf16 form (waves 4-7 issue none: any count passes); QK8: 6 for waves 0-3 (2 K + 4 V pieces), 1 for waves 4-5 (scales)
+#define A16_WAIT_TILE_AHEAD()                                                               \
+  do {                                                                                      \
+    if (!QK8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                              \
+    else if (wave < 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                     \
+    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                                   \
+  } while (0)
   A16_DMA(jt0, 0);
   if (jt0 + 1 < jt1) {
     A16_DMA(jt0 + 1, 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    A16_WAIT_TILE_AHEAD();
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -750,24 +807,56 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
   for (int u = 0; u < 3; ++u) {
     const int j = j0 + u;
     if (j >= jt1) break;
-    const char* sK = smem + u * AT_STAGE;
+    const char* sK = smem + u * STAGE;
     asm volatile("" : "+v"(d_k0), "+v"(d_k1), "+v"(d_k2), "+v"(d_k3), "+v"(d_v0), "+v"(d_v1), "+v"(d_v2), "+v"(d_v3));
     if (j + 2 < jt1) A16_DMA(j + 2, (u + 2) % 3);
 
     // ---------------- S^T blocks: fragment i = 4 kb + s read four ahead of its two MFMAs
     f32x4 sacc[4][2];
-    bf16x8 kf[16];
+    if (!QK8) {
+      bf16x8 kf[16];
 #define A16_KF(i) kf[i] = *reinterpret_cast<const bf16x8*>(sK + (((i) & 3) == 0 ? koff0 : ((i) & 3) == 1 ? koff1 : ((i) & 3) == 2 ? koff2 : koff3) + ((i) >> 2) * 4096)
-    A16_KF(0); A16_KF(1); A16_KF(2); A16_KF(3);
+      A16_KF(0); A16_KF(1); A16_KF(2); A16_KF(3);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      if (i + 4 < 16) { A16_KF(i + 4); }
-      __builtin_amdgcn_sched_barrier(0);
-      const int kb = i >> 2, s = i & 3;
-      sacc[kb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i], qf[0][s], s == 0 ? sinit[0] : sacc[kb][0], 0, 0, 0);
-      sacc[kb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i], qf[1][s], s == 0 ? sinit[1] : sacc[kb][1], 0, 0, 0);
-    }
+      for (int i = 0; i < 16; ++i) {
+        if (i + 4 < 16) { A16_KF(i + 4); }
+        __builtin_amdgcn_sched_barrier(0);
+        const int kb = i >> 2, s = i & 3;
+        sacc[kb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i], qf[0][QK8 ? 0 : s], s == 0 ? sinit[0] : sacc[kb][0], 0, 0, 0);
+        sacc[kb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i], qf[QK8 ? 0 : 1][QK8 ? 0 : s], s == 0 ? sinit[1] : sacc[kb][1], 0, 0, 0);
+      }
 #undef A16_KF
+    } else {
+      // int8: fragment i = 2 kb + s (d-slices of 64) on v_mfma_i32_16x16x64_i8; the accumulators START at the bit pattern of
+      // 12582912.0f (see attn_fwd_kernel), so their bits read as a float are 12582912 + dot, and one fma per score with the
+      // key's scale and its precomputed constant gives t = dot * delta_k
+      v4i ia[4][2], kf8[8];
+      const v4i mg = {0x4B400000, 0x4B400000, 0x4B400000, 0x4B400000};
+      f32x4 sk[4], sb[4];  // key scales / constants of the lane's four keys per key block: keys 16 kb + 4 pi(g) + e
+      const uint32_t sa = lds_base + u * STAGE + AT_SC8 + 16 * pg;
+#define A16_SC(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(sa), "n"(off))
+      A16_SC(sk[0], 0); A16_SC(sk[1], 64); A16_SC(sk[2], 128); A16_SC(sk[3], 192);
+      A16_SC(sb[0], 256); A16_SC(sb[1], 320); A16_SC(sb[2], 384); A16_SC(sb[3], 448);
+#define A16_KF8(i) kf8[i] = *reinterpret_cast<const v4i*>(sK + (((i) & 1) == 0 ? k8off0 : k8off1) + ((i) >> 1) * 2048)
+      A16_KF8(0); A16_KF8(1); A16_KF8(2); A16_KF8(3);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (i + 4 < 8) { A16_KF8(i + 4); }
+        __builtin_amdgcn_sched_barrier(0);
+        const int kb = i >> 1, s = i & 1;
+        ia[kb][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf8[i], qf8[0][QK8 ? s : 0], s == 0 ? mg : ia[kb][0], 0, 0, 0);
+        ia[kb][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf8[i], qf8[QK8 ? 1 : 0][QK8 ? s : 0], s == 0 ? mg : ia[kb][1], 0, 0, 0);
+      }
+#undef A16_KF8
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sk[0]), "+v"(sk[1]), "+v"(sk[2]), "+v"(sk[3]), "+v"(sb[0]), "+v"(sb[1]), "+v"(sb[2]), "+v"(sb[3]));
+#undef A16_SC
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sacc[kb][nq][e] = fmaf(__int_as_float(ia[kb][nq][e]), sk[kb][e], sb[kb][e]);
+    }
     if (j == nt - 1 && (p.Lk & (AT_KB - 1))) {  // ragged last tile: keys >= Lk get -inf
       asm volatile("" ::: "memory");
       const int kbase = j * AT_KB + 4 * pg;
@@ -785,7 +874,28 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
 #pragma unroll
       for (int e = 0; e < 4; ++e) { mx0 = fmaxf(mx0, sacc[kb][0][e]); mx1 = fmaxf(mx1, sacc[kb][1][e]); }
     const bool first = (j == jt0);
-    if (first || __any(fmaxf(mx0, mx1) > 6.0f)) {
+    if (QK8) {
+      // scores are dot * delta_k here; c2 = delta_q * scale * log2(e) is per lane and query block.  Running maximum in score
+      // units, rescaled lazily (first tile: m_run = -inf, so the vote fires and alpha = 0 on the zero accumulators)
+      if (__any(fmaxf((mx0 - m_run[0]) * c2[0], (mx1 - m_run[1]) * c2[1]) > 6.0f)) {
+        asm volatile("" ::: "memory");
+        float mx[2] = {mx0, mx1};
+#pragma unroll
+        for (int nq = 0; nq < 2; ++nq) {
+          float m = mx[nq];
+          m = fmaxf(m, __shfl_xor(m, 16, 64));
+          m = fmaxf(m, __shfl_xor(m, 32, 64));
+          const float m_new = fmaxf(m_run[nq], m);
+          const float alpha = __builtin_amdgcn_exp2f((m_run[nq] - m_new) * c2[nq]);
+          m_run[nq] = m_new;
+          l_run[nq] *= alpha;
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[i][nq][r] *= alpha;
+        }
+      }
+    } else if (first || __any(fmaxf(mx0, mx1) > 6.0f)) {
       asm volatile("" ::: "memory");  // keep this a branch
       float mx[2] = {mx0, mx1};
 #pragma unroll
@@ -813,10 +923,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
     }
     // P of key slice ks (32 keys) for query block nq: element j = 4 (kb & 1) + e of S block kb = 2 ks + (j >> 2)
     float ls0 = 0.f, ls1 = 0.f;
+    const float mc[2] = {QK8 ? m_run[0] * c2[0] : 0.f, QK8 ? m_run[1] * c2[1] : 0.f};
     bf16x8 pf[2][2];
 #define A16_EXP(kb, nq, e)                                                     \
   {                                                                            \
-    const float x_ = __builtin_amdgcn_exp2f(sacc[kb][nq][e]);                  \
+    const float x_ = __builtin_amdgcn_exp2f(QK8 ? fmaf(sacc[kb][nq][e], c2[nq], -mc[nq]) : sacc[kb][nq][e]); \
     if (nq == 0) { ls0 += x_; asm volatile("" : "+v"(ls0)); }                  \
     else { ls1 += x_; asm volatile("" : "+v"(ls1)); }                          \
     pf[(kb) >> 1][nq][4 * ((kb) & 1) + (e)] = (__bf16)x_;                      \
@@ -824,9 +935,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
 #define A16_EXP4(kb, nq) A16_EXP(kb, nq, 0) A16_EXP(kb, nq, 1) A16_EXP(kb, nq, 2) A16_EXP(kb, nq, 3)
 
     // ---------------- O^T += V^T . P^T
-    const uint32_t vb = lds_base + u * AT_STAGE;
+    const uint32_t vb = lds_base + u * STAGE;
     s16x4 ta0, ta1, ta2, ta3, ta4, ta5, ta6, ta7, tb0, tb1, tb2, tb3, tb4, tb5, tb6, tb7;
-#define A16_TR(dst, areg, ks, jh) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(vb + areg), "n"(AT_TILE + 8192 * (ks) + 4096 * (jh)))
+#define A16_TR(dst, areg, ks, jh) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(vb + areg), "n"(VOFF + 8192 * (ks) + 4096 * (jh)))
 #define A16_TR8(P, ks, a0_, a1_, a2_, a3_)                                                                      \
   A16_TR(P##0, a0_, ks, 0); A16_TR(P##1, a0_, ks, 1); A16_TR(P##2, a1_, ks, 0); A16_TR(P##3, a1_, ks, 1);     \
   A16_TR(P##4, a2_, ks, 0); A16_TR(P##5, a2_, ks, 1); A16_TR(P##6, a3_, ks, 0); A16_TR(P##7, a3_, ks, 1)
@@ -867,12 +978,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
 #undef A16_PV
 #undef A16_F
     // tile j+1 must have landed; the eight instructions of tile j+2 (if issued; waves 4-7 issue none) may stay in flight
-    if (j + 2 < jt1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (j + 2 < jt1) A16_WAIT_TILE_AHEAD();
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
   }
 #undef A16_DMA
+#undef A16_DMA8
+#undef A16_WAIT_TILE_AHEAD
 #undef A16_DMA_F
 #undef A16_DMA_S
 
@@ -891,7 +1004,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
           *reinterpret_cast<float4*>(po + 16 * db) = make_float4(o[db][nq][0], o[db][nq][1], o[db][nq][2], o[db][nq][3]);
         if (g4 == 0) {
           float* pm = p.part_ml + (((int64_t)blockIdx.z * p.Lq + qs) * p.H + head) * 2;
-          pm[0] = m_run[nq] / p.c;  // the merge kernel computes exp2((m - M) * p.c): m in raw-score units
+          // the merge kernel computes exp2((m - M) * p.c): hand it m in raw-score units (QK8: fold this query's delta_q in;
+          // bf16 form: m_run already carries scale * log2(e))
+          pm[0] = QK8 ? m_run[nq] * (c2[nq] / p.c) : m_run[nq] / p.c;
           pm[1] = l;
         }
       }
@@ -971,8 +1086,10 @@ static void launch_attn(const AttnParams& p, dim3 grid, hipStream_t st) {
 static bool use_m16() {
   static const bool m16 = [] {
     const char* e = getenv("WANQ_ATTN_M16");
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * AT_STAGE);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * AT_STAGE);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd16_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * AT_STAGE);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd16_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * AT_STAGE);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd16_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * AT_STAGE8);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * AT_STAGE8);
     return e ? e[0] == '1' : (WANQ_ATTN_M16_DEFAULT != 0);
   }();
   return m16;
@@ -1022,7 +1139,8 @@ static int attention_impl(const void* q, const void* k, const void* v, void* o, 
   hipStream_t st = (hipStream_t)stream;
   if (splits <= 1) {
     if (q8) {
-      launch_attn<false, true>(p, grid, st);
+      if (use_m16()) hipLaunchKernelGGL((attn_fwd16_kernel<false, true>), grid, dim3(512), 3 * AT_STAGE8, st, p);
+      else launch_attn<false, true>(p, grid, st);
     } else if (v1) {
       static const bool attr_v1 = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_STAGE);
@@ -1031,7 +1149,7 @@ static int attention_impl(const void* q, const void* k, const void* v, void* o, 
       (void)attr_v1;
       hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(512), 2 * AT_STAGE, st, p);
     } else if (use_m16()) {
-      hipLaunchKernelGGL(attn_fwd16_kernel<false>, grid, dim3(512), 3 * AT_STAGE, st, p);
+      hipLaunchKernelGGL((attn_fwd16_kernel<false, false>), grid, dim3(512), 3 * AT_STAGE, st, p);
     } else {
       launch_attn<false, false>(p, grid, st);
     }
@@ -1063,8 +1181,9 @@ static int attention_impl(const void* q, const void* k, const void* v, void* o, 
   p.part_o = static_cast<float*>(workspace);
   p.part_ml = p.part_o + (int64_t)splits * Lq * heads * AT_D;
   grid.z = (unsigned)splits;
-  if (q8) launch_attn<true, true>(p, grid, st);
-  else if (use_m16()) hipLaunchKernelGGL(attn_fwd16_kernel<true>, grid, dim3(512), 3 * AT_STAGE, st, p);
+  if (q8 && use_m16()) hipLaunchKernelGGL((attn_fwd16_kernel<true, true>), grid, dim3(512), 3 * AT_STAGE8, st, p);
+  else if (q8) launch_attn<true, true>(p, grid, st);
+  else if (use_m16()) hipLaunchKernelGGL((attn_fwd16_kernel<true, false>), grid, dim3(512), 3 * AT_STAGE, st, p);
   else launch_attn<true, false>(p, grid, st);
   const int64_t threads = Lq * heads * (AT_D / 4);
   hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p, splits);
