@@ -102,6 +102,32 @@ def test_epilogue_variants_fp32_vectors(out_dtype, M, N, K):
     assert torch.equal(buf, y)
 
 
+@pytest.mark.parametrize("M,N,K", [(32760, 1536, 256), (32760, 1536, 1536), (9450, 5120, 384)])
+def test_fp32_gate_residual_in_place_many_tiles(M, N, K):
+    """The fp32 + gate + residual epilogue of the persistent kernel prefetches the residual lines by LDS-DMA into the stage the
+    NEXT tile's first K-tile is loaded into: several tiles per workgroup, a short K (the store loop dominates, waves drift
+    apart), a ragged last m-tile, in place, repeated -- against the epilogue recomputed in torch from the exact accumulators."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a = torch.randint(-128, 128, (M, K), dtype=torch.int8, device=DEV, generator=g)
+    w = torch.randint(-128, 128, (N, K), dtype=torch.int8, device=DEV, generator=g)
+    sa = torch.rand(M, device=DEV, generator=g) * 0.01 + 1e-3
+    asum = a.float().sum(1) * sa
+    sw = torch.rand(N, device=DEV, generator=g) * 0.01 + 1e-3
+    zp = torch.randn(N, device=DEV, generator=g).round()
+    bias = torch.randn(N, device=DEV, generator=g)
+    gate = torch.randn(N, device=DEV, generator=g)
+    res = torch.randn(M, N, device=DEV, generator=g)
+    acc = qgemm().w8a8_o32(a, w).double()
+    ref = res.double() + gate.double()[None, :] * (acc * sa.double()[:, None] * sw.double()[None, :] +
+                                                   asum.double()[:, None] * (zp.double() * sw.double())[None, :] + bias.double()[None, :])
+    scale = ref.abs().max().item()
+    for _ in range(5):
+        buf = res.clone()
+        qgemm().w8a8_linear(a, w, sa, sw, bias, asum, zp, out_dtype=torch.float32, gate=gate, residual=buf, out=buf)
+        err = (buf.double() - ref).abs().max().item()
+        assert torch.isfinite(buf).all() and err < 1e-5 * scale, err
+
+
 def test_qlinear_module_from_linear_and_forward():
     """W8A8OF16LinearDynamicInputScale.from_linear + forward == fake-quant linear on the same codes."""
     from viditq_extension.nn import LayerNormGeneral, QuantParams, W8A8OF16LinearDynamicInputScale  # noqa: F401

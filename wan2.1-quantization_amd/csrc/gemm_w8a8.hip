@@ -311,6 +311,83 @@ constexpr int B2_STAGE = (B2M + B2N) * B2K;  // 64 KiB
 // = 16 codes of its operand with ONE ds_read_b64 and expands them in registers (and / shift+and).  LDS image of the packed
 // panel: 64-B rows, 16-B pieces XORed with (row>>2)&3 (conflict-free for the b64 lane groups, and a whole 16-B piece moves, so
 // the DMA source stays 16 B contiguous).
+// Store loop of the fp32 + gate + residual epilogue (the o / cross_attn.o / ffn.2 projections) with the residual lines PREFETCHED
+// ONE CHUNK AHEAD BY LDS-DMA.  Read where they are used, the residual lines cost every chunk a full memory latency (the C x C
+// GEMM ran 154 us against 91 us without that load; with the prefetch 129 us, K = 8960 447 -> 420 us; tools/ab_gemm_variants.py).
+// Chunk c = 2 J + ih = 32 tokens x 32 channels; its four 1-KiB residual pieces go to rbuf + (c & 1) * 4096, lane-linear (the lane
+// that fetched a 16-B piece reads it back): no registers, counted vmcnt waits (the four stores of chunk c-1 and the four pieces
+// of chunk c+1 may stay in flight).  rbuf lives in stage 0: the CALLER puts a workgroup barrier between this loop and the next
+// tile's first LDS-DMA, which lands in the other waves' buffers (tests/test_gpu_gemm.py::test_fp32_gate_residual_in_place_many_tiles
+// fails on every shape without it).  Requesting chunks 0 and 1 already behind the main loop's last barrier was measured too:
+// +3 % at K = 1536, -2 % at K = 13824, two spilled registers in the W4 form: not kept.
+// A function of its own for its __restrict__ parameters: hipcc puts s_waitcnt vmcnt(0) in front of every LDS access that may
+// alias an LDS-DMA in flight, i.e. in front of the turn-buffer writes right behind the prefetch (seen in the ISA); with the three
+// LDS regions as distinct restrict pointers it knows they do not.
+typedef int gemm_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void b2_store_f32_res(const GemmParams& p, gemm_v4i (&acc)[4][8], const float (&sa_m)[8], const float (&asum_m)[8],
+                                                 const float* __restrict__ chan, char* __restrict__ tb, char* __restrict__ rbuf, int cur_n0,
+                                                 int tok_base, int wn, int e16, int eq4, int rd_row, int rd_c, int lane_e, bool full_tile) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef __attribute__((address_space(1))) const void glb_void;
+  // rows past M / channels past N are clamped: fetched, never stored
+#define B2_RES_DMA(c)                                                                                          \
+  _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                                           \
+    int tok_ = tok_base + ((c) >> 1) * 32 + rd_row + 8 * ps, n_ = cur_n0 + wn * 64 + ((c) & 1) * 32 + rd_c * 4; \
+    tok_ = tok_ < p.M ? tok_ : p.M - 1;                                                                        \
+    n_ = n_ + 4 <= p.N ? n_ : p.N - 4;                                                                         \
+    __builtin_amdgcn_global_load_lds((glb_void*)(static_cast<const float*>(p.residual) + (int64_t)tok_ * p.N + n_), \
+                                     (lds_void*)(rbuf + ((c) & 1) * 4096 + ps * 1024), 16, 0, 0);              \
+  }
+  B2_RES_DMA(0)
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int J = c >> 1, ih = c & 1;
+    if (c + 1 < 8) { B2_RES_DMA(c + 1) }
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = 2 * J + jj, tr = jj * 16 + e16;
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = 2 * ih + ii;
+        char* dst = tb + tr * 128 + (((4 * ii + eq4) ^ (tr & 7)) << 4);
+        const int nl = wn * 64 + i * 16 + 4 * eq4;
+        const float4 sw4 = *reinterpret_cast<const float4*>(chan + nl);
+        const float4 zs4 = *reinterpret_cast<const float4*>(chan + 256 + nl);
+        const float4 b4 = *reinterpret_cast<const float4*>(chan + 512 + nl);
+        const float swa[4] = {sw4.x, sw4.y, sw4.z, sw4.w}, zsa[4] = {zs4.x, zs4.y, zs4.z, zs4.w};
+        const float ba[4] = {b4.x, b4.y, b4.z, b4.w};
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = fmaf((float)acc[i][j][e] * sa_m[j], swa[e], fmaf(asum_m[j], zsa[e], ba[e]));
+        if (p.epi & WANQ_EPI_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_fast_f32(y[e]);
+        }
+        *reinterpret_cast<float4*>(dst) = make_float4(y[0], y[1], y[2], y[3]);
+      }
+    }
+    // chunk c's pieces have landed; the stores of chunk c-1 and the pieces of chunk c+1 may still fly.  The counts hold for a
+    // full tile only: in a ragged one a wave skips whole store instructions (rows past M), so it drains instead.
+    if (!full_tile) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (c == 0 || c == 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int row = rd_row + 8 * ps;
+      const int tok = tok_base + J * 32 + row;
+      const int nl = wn * 64 + ih * 32 + rd_c * 4;
+      const int n = cur_n0 + nl;
+      if (!(full_tile || (tok < p.M && n < p.N))) continue;
+      const float4 v = *reinterpret_cast<const float4*>(tb + row * 128 + ((rd_c ^ (row & 7)) << 4));
+      const float4 rv = *reinterpret_cast<const float4*>(rbuf + (c & 1) * 4096 + ps * 1024 + lane_e * 16);
+      const float4 g4 = *reinterpret_cast<const float4*>(chan + 768 + nl);
+      *reinterpret_cast<float4*>(static_cast<float*>(p.out) + (int64_t)tok * p.N + n) =
+          make_float4(fmaf(v.x, g4.x, rv.x), fmaf(v.y, g4.y, rv.y), fmaf(v.z, g4.z, rv.z), fmaf(v.w, g4.w, rv.w));
+    }
+  }
+#undef B2_RES_DMA
+}
+
 template <int OUT, bool W4>
 __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -594,6 +671,9 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
             *reinterpret_cast<uint4*>(static_cast<uint16_t*>(p.out) + (int64_t)tok * p.N + n) = v;
         }
       }
+    } else if (OUT == WANQ_F32 && has_res) {
+      // stage 0 is free until the next tile's first K-tile is requested, which this path does after the store loop
+      b2_store_f32_res(p, acc, sa_m, asum_m, chan, tb, smem + wave * 8192, cur_n0, tok_base, wn, e16, eq4, rd_row, rd_c, lane_e, full_tile);
     } else {
       // chunk = 32 tokens x 32 channels (channel blocks 2 ih, 2 ih + 1) of fp32 / int32; gate*y + residual is applied after
       // the turn, on whole lines
@@ -665,6 +745,9 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
     // A full tile issues exactly 16 (16-bit output) or 32 store instructions per wave after the LDS-DMA above; a ragged
     // tile may issue fewer (whole-wave skips), so it falls back to a full drain.
     if (has_res) {
+      // fp32 + residual: every wave's residual buffers live in stage 0, which the next tile's first K-tile is about to fill
+      // (wave w's pieces land in the buffers of waves g and 4 + g): all waves must be out of the store loop first
+      if (OUT == WANQ_F32) __builtin_amdgcn_s_barrier();
       B2_ISSUE(0, 0);  // behind the stores: the first barrier of the next tile drains them (vmcnt(0))
       pending_stores = 0;
     } else {
