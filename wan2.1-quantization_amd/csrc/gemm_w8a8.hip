@@ -388,6 +388,71 @@ __device__ __forceinline__ void b2_store_f32_res(const GemmParams& p, gemm_v4i (
 #undef B2_RES_DMA
 }
 
+// 16-bit store loop (no residual) TOGETHER WITH the request of the next tile's first K-tile, in one function with the LDS regions
+// as __restrict__ parameters.  In the kernel body hipcc put s_waitcnt vmcnt(0) in front of the first LDS read behind that request
+// (the per-channel values; it cannot tell stage 0 from stage 1), so the prefetch that was meant to fly under the store loop was
+// waited for on the spot, once per tile (seen in the ISA).  Inside this function the request carries the noalias scopes of
+// `chan` and `tb` and no wait is inserted: the stores queue up behind the LDS-DMA and the next tile's first barrier counts them.
+template <int OUT, bool W4>
+__device__ __forceinline__ void b2_store16_and_request(const GemmParams& p, gemm_v4i (&acc)[4][8], const float (&sa_m)[8], const float (&asum_m)[8],
+                                                       const float* __restrict__ chan, char* __restrict__ tb, char* __restrict__ stage0, bool request,
+                                                       const uint32_t (&srcx)[4], const uint32_t (&srcw)[4], int wave, int cur_n0, int tok_base, int wn,
+                                                       int e16, int eq4, int rd_row, int rd_c, bool full_tile) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef __attribute__((address_space(1))) const void glb_void;
+  if (request) {  // K-tile 0 of the next tile -> stage 0 (the pieces of B2_ISSUE(0, 0))
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      __builtin_amdgcn_global_load_lds((glb_void*)(p.a + srcx[g]), (lds_void*)(stage0 + wave * 1024 + g * 8192), 16, 0, 0);
+      if (!W4 || g < 2)
+        __builtin_amdgcn_global_load_lds((glb_void*)(p.w + srcw[g]), (lds_void*)(stage0 + B2M * B2K + wave * 1024 + g * 8192), 16, 0, 0);
+    }
+  }
+  // chunk = 32 tokens (token blocks 2J, 2J+1) x 64 channels in the output type.  The lane's 16 channels (4 per channel block i)
+  // keep their three per-channel values in registers for the whole loop (48 registers; read per use they were 96 ds_read_b128
+  // per wave and tile).
+  float swa[4][4], zsa[4][4], ba[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int nl = wn * 64 + i * 16 + 4 * eq4;
+    const float4 sw4 = *reinterpret_cast<const float4*>(chan + nl);
+    const float4 zs4 = *reinterpret_cast<const float4*>(chan + 256 + nl);
+    const float4 b4 = *reinterpret_cast<const float4*>(chan + 512 + nl);
+    swa[i][0] = sw4.x; swa[i][1] = sw4.y; swa[i][2] = sw4.z; swa[i][3] = sw4.w;
+    zsa[i][0] = zs4.x; zsa[i][1] = zs4.y; zsa[i][2] = zs4.z; zsa[i][3] = zs4.w;
+    ba[i][0] = b4.x; ba[i][1] = b4.y; ba[i][2] = b4.z; ba[i][3] = b4.w;
+  }
+#pragma unroll
+  for (int J = 0; J < 4; ++J) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = 2 * J + jj, tr = jj * 16 + e16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)  // acc*sA*sW + (sumA*(zp*sW) + bias)
+          y[e] = fmaf((float)acc[i][j][e] * sa_m[j], swa[i][e], fmaf(asum_m[j], zsa[i][e], ba[i][e]));
+        if (p.epi & WANQ_EPI_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_fast_f32(y[e]);
+        }
+        const int cb = (i * 16 + 4 * eq4) * 2;  // byte column inside the 128-B row
+        *reinterpret_cast<uint2*>(tb + tr * 128 + ((((cb >> 4) ^ (tr & 7)) << 4) | (cb & 15))) = pack16x4<OUT>(y);
+      }
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int row = rd_row + 8 * ps;
+      const uint4 v = *reinterpret_cast<const uint4*>(tb + row * 128 + ((rd_c ^ (row & 7)) << 4));
+      const int tok = tok_base + J * 32 + row;
+      const int n = cur_n0 + wn * 64 + rd_c * 8;
+      if (full_tile || (tok < p.M && n < p.N))
+        *reinterpret_cast<uint4*>(static_cast<uint16_t*>(p.out) + (int64_t)tok * p.N + n) = v;
+    }
+  }
+}
+
 template <int OUT, bool W4>
 __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -605,10 +670,12 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
       }
       __syncthreads();
     }
+    constexpr bool OUT16 = (OUT == WANQ_F16 || OUT == WANQ_BF16);
     if (next < ntiles) {
       tile_origin(next, m0, n0);
       set_sources(m0, n0);
-      if (!has_res) B2_ISSUE(0, 0);
+      // the 16-bit no-residual path requests the next tile's first K-tile inside its store function (b2_store16_and_request)
+      if (!has_res && !OUT16) B2_ISSUE(0, 0);
     }
     const bool full_tile = (cur_m0 + B2M <= p.M) && (cur_n0 + B2N <= p.N);
     // ---- store loop.  An accumulator has one token per lane and 4 channels per register quad, so storing it directly
@@ -626,51 +693,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_big_kernel(const GemmParams 
     const int rd_row = lane_e >> 3, rd_c = lane_e & 7;  // read-back: row rd_row + 8*pass, 16-B chunk rd_c
     const int e16 = lane_e & 15, eq4 = lane_e >> 4;     // = r16, q4 (opaque copies)
     const int tok_base = cur_m0 + wm * 128;
-    constexpr bool OUT16 = (OUT == WANQ_F16 || OUT == WANQ_BF16);
     if (OUT16 && !has_res) {
-      // chunk = 32 tokens (token blocks 2J, 2J+1) x 64 channels in the output type.  The lane's 16 channels (4 per channel
-      // block i) keep their three per-channel values in registers for the whole loop (48 registers; read per use they were 96
-      // ds_read_b128 per wave and tile).
-      float swa[4][4], zsa[4][4], ba[4][4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int nl = wn * 64 + i * 16 + 4 * eq4;
-        const float4 sw4 = *reinterpret_cast<const float4*>(chan + nl);
-        const float4 zs4 = *reinterpret_cast<const float4*>(chan + 256 + nl);
-        const float4 b4 = *reinterpret_cast<const float4*>(chan + 512 + nl);
-        swa[i][0] = sw4.x; swa[i][1] = sw4.y; swa[i][2] = sw4.z; swa[i][3] = sw4.w;
-        zsa[i][0] = zs4.x; zsa[i][1] = zs4.y; zsa[i][2] = zs4.z; zsa[i][3] = zs4.w;
-        ba[i][0] = b4.x; ba[i][1] = b4.y; ba[i][2] = b4.z; ba[i][3] = b4.w;
-      }
-#pragma unroll
-      for (int J = 0; J < 4; ++J) {
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          const int j = 2 * J + jj, tr = jj * 16 + e16;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float y[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)  // acc*sA*sW + (sumA*(zp*sW) + bias)
-              y[e] = fmaf((float)acc[i][j][e] * sa_m[j], swa[i][e], fmaf(asum_m[j], zsa[i][e], ba[i][e]));
-            if (p.epi & WANQ_EPI_GELU) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_fast_f32(y[e]);
-            }
-            const int cb = (i * 16 + 4 * eq4) * 2;  // byte column inside the 128-B row
-            *reinterpret_cast<uint2*>(tb + tr * 128 + ((((cb >> 4) ^ (tr & 7)) << 4) | (cb & 15))) = pack16x4<OUT>(y);
-          }
-        }
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-          const int row = rd_row + 8 * ps;
-          const uint4 v = *reinterpret_cast<const uint4*>(tb + row * 128 + ((rd_c ^ (row & 7)) << 4));
-          const int tok = tok_base + J * 32 + row;
-          const int n = cur_n0 + wn * 64 + rd_c * 8;
-          if (full_tile || (tok < p.M && n < p.N))
-            *reinterpret_cast<uint4*>(static_cast<uint16_t*>(p.out) + (int64_t)tok * p.N + n) = v;
-        }
-      }
+      if (OUT16)  // (instantiated for the 16-bit output types only)
+        b2_store16_and_request<OUT16 ? OUT : WANQ_BF16, W4>(p, acc, sa_m, asum_m, chan, tb, smem, next < ntiles, srcx, srcw, wave, cur_n0, tok_base,
+                                                            wn, e16, eq4, rd_row, rd_c, full_tile);
     } else if (OUT == WANQ_F32 && has_res) {
       // stage 0 is free until the next tile's first K-tile is requested, which this path does after the store loop
       b2_store_f32_res(p, acc, sa_m, asum_m, chan, tb, smem + wave * 8192, cur_n0, tok_base, wn, e16, eq4, rd_row, rd_c, lane_e, full_tile);
