@@ -138,7 +138,8 @@ def test_weight_codes_and_params_match_oracle():
 
 
 @pytest.mark.parametrize("Lq,Lk,H,klen", [(32, 64, 1, None), (300, 300, 2, None), (256, 64, 3, None), (100, 512, 2, None),
-                                           (1000, 777, 2, None), (515, 640, 12, 601), (2050, 2050, 4, None)])
+                                           (1000, 777, 2, None), (515, 640, 12, 601), (2050, 2050, 4, None),
+                                           (1, 17, 1, None), (5, 63, 2, None), (17, 65, 1, 33)])  # one query, one ragged tile, a masked second tile
 def test_flash_attention_vs_fp32_softmax(Lq, Lk, H, klen):
     """No fixture of the reference pins attention (flash_attn is an external library): the pin is the fp32
     definition softmax(QK^T/sqrt(d))V on the same bf16 inputs.  Tolerance: P is rounded to bf16 before PV
