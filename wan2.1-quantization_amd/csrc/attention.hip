@@ -1,6 +1,10 @@
-// Flash-attention forward for gfx950 (bf16 MFMA 32x32x16), head_dim 128, non-causal, key-length masking.
+// Flash-attention forward for gfx950, head_dim 128, non-causal, key-length masking.
 //
 //   O[q, h, :] = softmax_k( Q[q,h,:] . K[k,h,:] / sqrt(d) ) V[k,h,:]
+//
+// Two kernels in this file: attn_fwd16_kernel (v_mfma_f32_16x16x32_bf16 / v_mfma_i32_16x16x64_i8; the default, described in
+// front of it further down) and attn_fwd_kernel (32x32x16 / 32x32x32; WANQ_ATTN_M16=0), described here -- the LDS-DMA ring,
+// the barrier protocol, the lazy rescale and the accumulator-initialised softmax are common to both.
 //
 // Layout: Q/K/V/O are token-major [tokens, heads*128] bf16 (exactly what the q/k/v GEMMs write and what the
 // o-projection's quantiser reads), so no head transposes exist anywhere.
