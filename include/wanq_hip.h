@@ -197,6 +197,21 @@ int wanq_attention_qk8_fwd(const int8_t* q8, const float* q_scale, int64_t qs_st
                            int64_t v_stride, int64_t o_stride, float scale, int splits, void* workspace,
                            int64_t workspace_bytes, void* stream);
 
+/* Attention with a QUANTISED ATTENTION MAP (the reference's `attn.attn_map` / `cross_attn.attn_map`, group 'row':
+ * QuantizedAttentionMapOpenSORA, ViDiT-Q/quant_utils/qdiff/base/quant_attn.py:118-173, applied between softmax and `attn @ v`
+ * at examples/Wan2.1/models/quant_opensora.py:459-476): every KEY column of the post-softmax map is one dynamic quantisation
+ * group shared by all queries (DynamicQuantizer, base_quantizer.py:101-162), which on a map in [0, 1] is
+ *   P~[q,k] = rne(P[q,k] / delta_k) * delta_k,  delta_k = max_q P[q,k] / L,  L = 2^(n_bits-1) - 1 (sym) or 2^n_bits - 1 (asym).
+ * The reference materialises the N x N map (and asserts against flash attention); this entry point streams it in three passes
+ * over the keys (row statistics, column maxima, quantised P.V), so it also runs at lengths where the map does not fit.  The map
+ * is kept in fp32 (the reference rounds it to the model's 16-bit dtype first when it runs under autocast).
+ * workspace: wanq_attention_map_workspace() bytes of device memory, 16-byte aligned.  q / k / v / o as in wanq_attention_fwd. */
+int64_t wanq_attention_map_workspace(int64_t Lq, int64_t Lk, int heads);
+int wanq_attention_map_quant_fwd(const void* q, const void* k, const void* v, void* o, int dtype, int64_t Lq, int64_t Lk,
+                                 int heads, int head_dim, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                 int64_t o_stride, float scale, int n_bits, int sym, void* workspace,
+                                 int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * ViDiT activation transform fused with the per-token quantiser:
  *   y = hadU(x * premul),   hadU = (H_K (x) H_128) / sqrt(cols)   (natural-order Walsh-Hadamard on each

@@ -136,14 +136,47 @@ def attention_qk_quant(q, k, v, k_len=None, n_bits=8):
     return attention(qk_fake_quant(q, n_bits), qk_fake_quant(k, n_bits), v, k_len)
 
 
+def attn_map_fake_quant(p, n_bits=8, sym=False):
+    """QuantizedAttentionMapOpenSORA.forward, group 'row' (Q/base/quant_attn.py:166-173): the post-softmax map [n, Lq, Lk] is
+    permuted so that every KEY column is one quantisation group (all queries share its parameters) and goes through the
+    DynamicQuantizer (Q/base/base_quantizer.py:101-162, restated here with both of its forms)."""
+    n, Lq, Lk = p.shape
+    x = p.permute(0, 2, 1).reshape(n * Lk, Lq)
+    if sym:
+        n_levels = 2 ** (n_bits - 1) - 1
+        delta = x.abs().max(dim=1)[0] / n_levels
+        zp = torch.zeros_like(delta)
+        delta[delta < 1e-6] = 1e-6
+    else:
+        n_levels = 2 ** n_bits
+        x_max = x.max(dim=1)[0].clamp(min=0.0)
+        x_min = x.min(dim=1)[0].clamp(max=0.0)
+        delta = (x_max - x_min) / (n_levels - 1)
+        delta[delta < 1e-8] = 1e-8
+        zp = torch.round(x_min / delta) + n_levels / 2
+    delta, zp = delta[:, None], zp[:, None]
+    xq = torch.clamp(torch.round(x / delta) - zp, -n_levels - 1, n_levels)
+    return ((xq + zp) * delta).reshape(n, Lk, Lq).permute(0, 2, 1)
+
+
+def attention_map_quant(q, k, v, k_len=None, n_bits=8, sym=False):
+    """attention() with the post-softmax map fake-quantised per key column before `attn @ v` (W/models/quant_opensora.py:459-476;
+    the map stays fp32 here, the reference casts it to the model dtype first)."""
+    if k_len is not None:
+        k, v = k[:k_len], v[:k_len]
+    s = torch.einsum("qnd,knd->nqk", q, k) / math.sqrt(q.shape[-1])
+    return torch.einsum("nqk,knd->qnd", attn_map_fake_quant(torch.softmax(s, dim=-1), n_bits, sym), v)
+
+
 class BlockRef:
     """One WanAttentionBlock in simulation mode.  `lin` maps 'self_attn.q' ... 'ffn.2' to callables."""
 
     def __init__(self, lin, norm_w, modulation, num_heads, eps=1e-6, norm3=None, qk_bits=None, cross_qk_bits=None, v_bits=None,
-                 cross_v_bits=None):
+                 cross_v_bits=None, attn_map=None, cross_attn_map=None):
         self.lin, self.norm_w, self.mod, self.n, self.eps, self.norm3 = lin, norm_w, modulation.float(), num_heads, eps, norm3
         self.qk_bits, self.cross_qk_bits = qk_bits, cross_qk_bits  # None = FP attention (the reference's Wan wiring)
         self.v_bits, self.cross_v_bits = v_bits, cross_v_bits
+        self.attn_map, self.cross_attn_map = attn_map, cross_attn_map  # (n_bits, sym) of the attention-map quantiser, or None
 
     def __call__(self, x, e0, grid, seq_len, context, freqs):
         """x [L, C], e0 [1, 6, C], context [Lc, C] -> x' [L, C]   (model.py:293-370 for B = 1)."""
@@ -160,7 +193,7 @@ class BlockRef:
             q, k = qk_fake_quant(q, self.qk_bits), qk_fake_quant(k, self.qk_bits)
         if self.v_bits:
             v = torch.cat([v_fake_quant(v[:seq_len], self.v_bits), v[seq_len:]])
-        o = attention(q, k, v, seq_len).reshape(L, C)
+        o = (attention_map_quant(q, k, v, seq_len, *self.attn_map) if self.attn_map else attention(q, k, v, seq_len)).reshape(L, C)
         x = x + self.lin["self_attn.o"](o) * e[2]
         h = layer_norm(x, self.eps, *(self.norm3 or (None, None)))
         q = rms_norm(self.lin["cross_attn.q"](h), self.norm_w["cross_attn.norm_q"], self.eps).view(L, n, d)
@@ -170,7 +203,8 @@ class BlockRef:
             q, k = qk_fake_quant(q, self.cross_qk_bits), qk_fake_quant(k, self.cross_qk_bits)
         if self.cross_v_bits:
             v = v_fake_quant(v, self.cross_v_bits)
-        x = x + self.lin["cross_attn.o"](attention(q, k, v).reshape(L, C))
+        o = attention_map_quant(q, k, v, None, *self.cross_attn_map) if self.cross_attn_map else attention(q, k, v)
+        x = x + self.lin["cross_attn.o"](o.reshape(L, C))
         h = layer_norm(x, self.eps) * (1 + e[4]) + e[3]
         y = self.lin["ffn.2"](F.gelu(self.lin["ffn.0"](h), approximate="tanh"))
         return x + y * e[5]
@@ -181,7 +215,7 @@ LINEARS = ("self_attn.q", "self_attn.k", "self_attn.v", "self_attn.o", "cross_at
 
 
 def block_from_state(sd, num_heads, eps=1e-6, quant=True, w_bits=8, a_bits=8, vidit=None, qk_bits=None, cross_qk_bits=None,
-                     v_bits=None, cross_v_bits=None):
+                     v_bits=None, cross_v_bits=None, attn_map=None, cross_attn_map=None):
     """Build a BlockRef from a WanAttentionBlock state dict (CPU tensors).
     vidit: optional {linear name: (channel_mask fp32 [K], rotation fp64 [K,K])}."""
     lin = {}
@@ -194,4 +228,4 @@ def block_from_state(sd, num_heads, eps=1e-6, quant=True, w_bits=8, a_bits=8, vi
             lin[name] = FpLinear(w, b)
     norm_w = {k: sd[k + ".weight"].float() for k in ("self_attn.norm_q", "self_attn.norm_k", "cross_attn.norm_q", "cross_attn.norm_k")}
     norm3 = (sd["norm3.weight"].float(), sd["norm3.bias"].float()) if "norm3.weight" in sd else None
-    return BlockRef(lin, norm_w, sd["modulation"], num_heads, eps, norm3, qk_bits, cross_qk_bits, v_bits, cross_v_bits)
+    return BlockRef(lin, norm_w, sd["modulation"], num_heads, eps, norm3, qk_bits, cross_qk_bits, v_bits, cross_v_bits, attn_map, cross_attn_map)

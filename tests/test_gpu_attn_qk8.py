@@ -164,8 +164,8 @@ def test_v_fake_quant_per_column_vs_oracle(rows, cols, dtype, bits):
 
 
 def test_kernel_mode_block_with_quantized_v_vs_oracle(tmp_path):
-    """attn.v / cross_attn.v (+ qk) through the quant config: block vs the simulation oracle with the same recipe; attn_map is
-    refused with the reason."""
+    """attn.v / cross_attn.v (+ qk) through the quant config: block vs the simulation oracle with the same recipe; attn_map group
+    'row' / 'column' is picked up, its 'block' mode refused with the reason."""
     from test_gpu_block import make_block, rel_err
     from wan import ops
     from wan.quant_wanx_hip import WanAttentionBlockWithHipKernel, _FpSrc
@@ -202,11 +202,17 @@ def test_kernel_mode_block_with_quantized_v_vs_oracle(tmp_path):
     m.set_init_done()
     m.hardware_forward_refactor()
     assert m.hip_blocks[0].attn_v_bits == 8 and m.hip_blocks[0].attn_qk8 and m.hip_blocks[0].cross_attn_v_bits is None
-    m2 = QuantWanModel.from_float(fp, qcfg.create(dict(base, attn={"attn_map": {"n_bits": 8, "group": "column"}})))
+    m2 = QuantWanModel.from_float(fp, qcfg.create(dict(base, attn={"attn_map": {"n_bits": 8, "group": "block"}})))
     m2.quant_layer_refactor()
     m2.set_init_done()
-    with pytest.raises(NotImplementedError, match="attention map"):
+    with pytest.raises(NotImplementedError, match="CogVideoX"):  # the 'block' mode is tied to another model's grid and reorder tables
         m2.hardware_forward_refactor()
+    m3 = QuantWanModel.from_float(fp, qcfg.create(dict(base, attn={"attn_map": {"n_bits": 8, "sym": False, "group": "row"}},
+                                                       cross_attn={"attn_map": {"n_bits": 4, "sym": True, "group": "column"}})))
+    m3.quant_layer_refactor()
+    m3.set_init_done()
+    m3.hardware_forward_refactor()
+    assert m3.hip_blocks[0].attn_map == (8, False) and m3.hip_blocks[0].cross_attn_map == (4, True)
 
 
 @pytest.mark.parametrize("bits", [8, 4])
@@ -238,3 +244,71 @@ def test_qk_int8_codes_vs_reference_golden(golden):
         delta = q8.scales[0, :, :n_tok].t().contiguous()  # [tokens, heads]
         deq = q8.codes.float().view(n_tok, H, D) * delta.unsqueeze(-1)
         assert torch.equal(deq.view(n_tok, H * D).cpu(), ref)
+
+
+@pytest.mark.parametrize("Lq,Lk,H,klen,bits,sym", [(45, 45, 3, None, 8, False), (300, 300, 2, None, 8, True), (100, 512, 2, None, 8, False),
+                                                    (515, 640, 4, 601, 8, False), (130, 77, 1, None, 4, True), (1000, 777, 2, None, 8, False)])
+def test_attention_map_quant_vs_oracle(Lq, Lk, H, klen, bits, sym):
+    """The streamed attention-map quantiser (three passes: row statistics, column maxima, quantised P.V) against the oracle's
+    materialised form (oracle/wan_ref.py::attention_map_quant, pinned by the reference's own QuantizedAttentionMapOpenSORA in
+    tests/golden/a16_attn_map.npz): ragged query / key counts, key masking, cross shapes, 8 and 4 bits, both quantiser forms.
+    Tolerance: the flash-attention bar (P~ goes to the P.V MFMA as bf16) plus one quantisation step of a column."""
+    from wan import ops
+
+    d = 128
+    g = torch.Generator().manual_seed(Lq * 7 + Lk)
+    q = (torch.randn(Lq, H * d, generator=g) * 1.5).to(torch.bfloat16)
+    k = (torch.randn(Lk, H * d, generator=g) * 1.5).to(torch.bfloat16)
+    v = torch.randn(Lk, H * d, generator=g).to(torch.bfloat16)
+    if Lk > 70:
+        k[69] *= 3.0  # a dominant key column
+    ref = wr.attention_map_quant(q.float().view(Lq, H, d), k.float().view(Lk, H, d), v.float().view(Lk, H, d), klen, bits, sym).reshape(Lq, H * d)
+    fp = wr.attention(q.float().view(Lq, H, d), k.float().view(Lk, H, d), v.float().view(Lk, H, d), klen).reshape(Lq, H * d)
+    out = ops.attention_map_quant(q.to(DEV), k.to(DEV), v.to(DEV), H, bits, sym, klen).float().cpu()
+    err, noise = (out - ref).norm() / ref.norm(), (ref - fp).norm() / fp.norm()
+    levels = (2 ** (bits - 1) - 1) if sym else (2 ** bits - 1)
+    # a code may flip at a .5 boundary (the map is recomputed, exp2-based, on the GPU): one step of a column (<= 1 / levels) times |v|
+    step = v.float().abs().max().item() / levels
+    assert torch.isfinite(out).all() and (out - ref).abs().max().item() < 3e-2 + 1.5 * step, (out - ref).abs().max().item()
+    assert err.item() < (1.2e-2 if bits == 8 else 0.5 * noise.item() + 1e-2), (err.item(), noise.item())  # 4 bits: well inside the recipe's own noise
+
+
+def test_attention_map_quant_matches_reference_golden(golden=None):
+    """The same entry point on the inputs of the reference-generated fixture (q, k, v as bf16): against the reference's own
+    `attn_quantised @ v`."""
+    import os
+
+    from wan import ops
+
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "a16_attn_map.npz")))
+    q, k, v = (torch.from_numpy(g[n])[0].permute(1, 0, 2).reshape(45, 3 * 128).to(torch.bfloat16) for n in ("q", "k", "v"))
+    for tag, bits, sym in (("8a", 8, False), ("8s", 8, True), ("4s", 4, True)):
+        out = ops.attention_map_quant(q.to(DEV), k.to(DEV), v.to(DEV), 3, bits, sym).float().cpu().view(45, 3, 128)
+        ref = torch.from_numpy(g[f"x_{tag}"])[0].permute(1, 0, 2)
+        # the fixture's q / k / v are fp32; rounding them to bf16 for the kernel moves the scores by 2^-8 relative
+        assert ((out - ref).norm() / ref.norm()).item() < (6e-2 if bits == 4 else 3e-2)
+
+
+def test_kernel_mode_block_with_quantized_attention_map_vs_oracle():
+    """attn.attn_map / cross_attn.attn_map: kernel-mode block (all linears W8A8, streamed attention-map quantiser in both
+    attentions) vs the simulation oracle with the same recipe (BlockRef(attn_map=...), materialised map)."""
+    from test_gpu_block import make_block, rel_err
+    from wan import ops
+    from wan.quant_wanx_hip import WanAttentionBlockWithHipKernel, _FpSrc
+
+    dim, ffn, heads, grid, lc = 512, 1024, 4, (2, 6, 8), 64
+    blk = make_block(dim, ffn, heads, 0)
+    sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    n_tok = grid[0] * grid[1] * grid[2]
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n_tok, dim, generator=g)
+    e0 = torch.randn(1, 6, dim, generator=g) * 0.3
+    ctx = torch.randn(lc, dim, generator=g)
+    freqs = wr.rope_freqs(dim // heads)
+    ref = wr.block_from_state(sd, heads, quant=True, attn_map=(8, False), cross_attn_map=(8, True))(x, e0, grid, n_tok, ctx, freqs)
+    ref_fp_map = wr.block_from_state(sd, heads, quant=True)(x, e0, grid, n_tok, ctx, freqs)
+    hb = WanAttentionBlockWithHipKernel.from_float(blk.to(DEV), attn_map=(8, False), cross_attn_map=(8, True))
+    out = hb(x.to(DEV).clone(), e0.to(DEV), ops.rope_table(freqs, grid, DEV), n_tok, _FpSrc(ctx.to(DEV), torch.bfloat16)).float().cpu()
+    err = rel_err(out, ref)
+    print(f"block with quantised attention map: rel err vs recipe oracle {err:.2e}; recipe vs FP-map oracle {rel_err(ref, ref_fp_map):.2e}")
+    assert err < 1e-2

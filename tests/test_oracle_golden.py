@@ -219,3 +219,24 @@ def test_a16_attention_qkv_quantisers_vs_reference(golden, bits):
         assert torch.equal(wr.qk_fake_quant(x, bits), ref)
     v = torch.from_numpy(g["v"])[0].permute(1, 0, 2).contiguous()
     assert torch.equal(wr.v_fake_quant(v, bits), torch.from_numpy(g[f"v{bits}"])[0].permute(1, 0, 2))
+
+
+@pytest.mark.parametrize("tag,bits,sym", [("8a", 8, False), ("8s", 8, True), ("4s", 4, True)])
+def test_a16_attention_map_quantiser_vs_reference(golden, tag, bits, sym):
+    """oracle/wan_ref.py attn_map_fake_quant / attention_map_quant == the reference's QuantizedAttentionMapOpenSORA (group 'row':
+    one dynamic group per key column over all queries, quant_attn.py:166-173) on a seeded post-softmax map, and the `attn @ v` it
+    feeds (quant_opensora.py:459-476).  Fixture: tests/golden/make_golden_attn_map.py (the reference's own module)."""
+    import torch
+
+    from oracle import wan_ref as wr
+
+    g = golden("a16_attn_map")
+    attn = torch.from_numpy(g["attn"])[0]                                   # [H, N, N]
+    assert torch.equal(wr.attn_map_fake_quant(attn, bits, sym), torch.from_numpy(g[f"attn_q_{tag}"])[0])
+    q, k, v = (torch.from_numpy(g[n])[0].permute(1, 0, 2).contiguous() for n in ("q", "k", "v"))  # [B, H, N, D] -> [N, H, D]
+    x = wr.attention_map_quant(q, k, v, None, bits, sym)                     # [N, H, D]
+    ref = torch.from_numpy(g[f"x_{tag}"])[0].permute(1, 0, 2)
+    # the softmax map is recomputed here (einsum order differs from the reference's q @ k^T by an fp32 rounding): a code may move
+    # at a .5 boundary, i.e. by one step of a column whose maximum is <= 1
+    assert (x - ref).abs().max().item() < 2.0 / (2 ** (bits - 1) - 1) * v.abs().max().item()
+    assert ((x - ref).norm() / ref.norm()).item() < 2e-3

@@ -50,6 +50,8 @@ PROTOTYPES = {
     "wanq_attention_fwd": [_vp, _vp, _vp, _vp, _i, _i64, _i64, _i, _i, _i64, _i64, _i64, _i64, _f, _vp],
     "wanq_attention_fwd_split": [_vp, _vp, _vp, _vp, _i, _i64, _i64, _i, _i, _i64, _i64, _i64, _i64, _f, _i, _vp, _i64, _vp],
     "wanq_attention_split_workspace": [_i64, _i, _i, _i],
+    "wanq_attention_map_workspace": [_i64, _i64, _i],
+    "wanq_attention_map_quant_fwd": [_vp, _vp, _vp, _vp, _i, _i64, _i64, _i, _i, _i64, _i64, _i64, _i64, _f, _i, _i, _vp, _i64, _vp],
 }
 for _name, _args in PROTOTYPES.items():
     _fn = getattr(lib, _name)  # AttributeError here = header and library out of sync
@@ -57,6 +59,7 @@ for _name, _args in PROTOTYPES.items():
     _fn.restype = ctypes.c_int
 lib.wanq_last_error.restype = ctypes.c_char_p
 lib.wanq_attention_split_workspace.restype = ctypes.c_int64
+lib.wanq_attention_map_workspace.restype = ctypes.c_int64
 lib.wanq_abi_version.restype = ctypes.c_int
 if lib.wanq_abi_version() != ABI_VERSION:
     raise ImportError(f"libwanq_hip.so ABI {lib.wanq_abi_version()} != binding ABI {ABI_VERSION}; rebuild")

@@ -126,6 +126,31 @@ def attention_qk8(q8, k8, v, num_heads, k_len=None, out=None, splits=None):
     return out
 
 
+def attention_map_quant(q, k, v, num_heads, n_bits=8, sym=False, k_len=None, out=None):
+    """softmax(q k^T / sqrt(d)) with every KEY column of the map fake-quantised over all queries, then @ v -- the reference's
+    `attn.attn_map` recipe, group 'row' (Q/base/quant_attn.py:118-173), streamed in three passes (csrc/attn_map.hip).
+    q [Lq, C], k / v [Lk, C] bf16 -> [Lq, C]."""
+    Lq, C = q.shape
+    d = C // num_heads
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        _C.check_gpu(n, t)
+        _C.check_dtype(n, t, torch.bfloat16)
+        if t.dim() != 2 or t.shape[1] != C or t.stride(1) != 1:
+            raise RuntimeError(f"Tensor {n} must be [tokens, {C}] with unit column stride")
+    if k.shape[0] != v.shape[0]:
+        raise RuntimeError("k and v must have the same number of tokens")
+    Lk = k.shape[0] if k_len is None else min(int(k_len), k.shape[0])
+    if out is None:
+        out = torch.empty(Lq, C, dtype=q.dtype, device=q.device)
+    nbytes = _C.lib.wanq_attention_map_workspace(Lq, Lk, num_heads)
+    ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        _C.call("wanq_attention_map_quant_fwd", _C.ptr(q), _C.ptr(k), _C.ptr(v), _C.ptr(out), _C.dt(q), Lq, Lk, num_heads, d,
+                q.stride(0), k.stride(0), v.stride(0), out.stride(0), 1.0 / math.sqrt(d), int(n_bits), 1 if sym else 0, _C.ptr(ws),
+                nbytes, _C.stream())
+    return out
+
+
 def rope_table(freqs, grid, device):
     """(cos, sin) table fp32 [f*h*w, d/2, 2] for one (f,h,w) grid from the model's complex freqs [1024, d/2]
     -- the `freqs_i` of rope_apply (wan/modules/model.py:56-61), built once per grid in float64."""

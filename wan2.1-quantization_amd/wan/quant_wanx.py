@@ -114,7 +114,7 @@ class QuantWanModel(WanModel, QuantModel):
         reference does with `int_weight.pt`: codes, scales, zero points, biases and activation pre-multipliers of every
         quantized Linear come from the file (either format of quantize_and_save_weight), a quantized Linear without its keys
         or with a shape mismatch is an error, and the number of tensors taken is logged."""
-        qk8, vb = {}, {}
+        qk8, vb, amap = {}, {}, {}
         for key in ("attn", "cross_attn"):  # quant_config.attn.qk / cross_attn.qk (Q/base/quant_attn.py:19-29,130-143)
             sub = self.q_cfg.get(key, None) if self.q_cfg is not None else None
             qk = sub.get("qk", None) if sub is not None else None
@@ -127,14 +127,19 @@ class QuantWanModel(WanModel, QuantModel):
                 if not vq.get("sym", True):
                     raise NotImplementedError(f"{key}.v: symmetric v quantisation is implemented (the reference's DynamicQuantizer default)")
                 vb[key] = int(vq.get("n_bits", 8))
-            if sub is not None and sub.get("attn_map", None) is not None:
-                raise NotImplementedError(
-                    f"{key}.attn_map: the reference quantises the MATERIALISED attention map per key column / reordered block "
-                    "(Q/base/quant_attn.py:40-118) and refuses it under flash attention itself (quant_opensora.py:442-443); "
-                    "there is no streaming form of that recipe")
+            am = sub.get("attn_map", None) if sub is not None else None
+            if am is not None:  # post-softmax map, one dynamic group per KEY column (Q/base/quant_attn.py:166-173, group 'row')
+                if am.get("group", "row") not in ("row", "column"):  # the OpenSORA class calls it 'row', the CogVideoX class 'column': same code
+                    raise NotImplementedError(
+                        f"{key}.attn_map.group = {am.get('group')!r}: the 'block' mode of the reference is tied to CogVideoX's 13x30x45 grid "
+                        "and to per-head reorder tables (Q/base/quant_attn.py:176-236); 'row' is implemented (streamed, csrc/attn_map.hip)")
+                if qk8.get(key) or vb.get(key):
+                    raise NotImplementedError(f"{key}.attn_map together with {key}.qk / {key}.v is not implemented (one attention recipe at a time)")
+                amap[key] = (int(am.get("n_bits", 8)), bool(am.get("sym", False)))
         self.hip_blocks = nn.ModuleList([WanAttentionBlockWithHipKernel.from_float(
             b, None, False, act_dtype, attn_qk8=qk8.get("attn", False), cross_attn_qk8=qk8.get("cross_attn", False),
-            attn_v_bits=vb.get("attn"), cross_attn_v_bits=vb.get("cross_attn")) for b in self.blocks])
+            attn_v_bits=vb.get("attn"), cross_attn_v_bits=vb.get("cross_attn"), attn_map=amap.get("attn"),
+            cross_attn_map=amap.get("cross_attn")) for b in self.blocks])
         if load_path:
             sd = torch.load(load_path, map_location="cpu", weights_only=True)
             taken = 0

@@ -259,7 +259,7 @@ class _Attn(nn.Module):
 
 class WanAttentionBlockWithHipKernel(nn.Module):
     def __init__(self, dim, ffn_dim, num_heads, eps=1e-6, act_dtype=torch.bfloat16, attn_qk8=False, cross_attn_qk8=False,
-                 attn_v_bits=None, cross_attn_v_bits=None):
+                 attn_v_bits=None, cross_attn_v_bits=None, attn_map=None, cross_attn_map=None):
         super().__init__()
         self.dim, self.ffn_dim, self.num_heads, self.head_dim, self.eps = dim, ffn_dim, num_heads, dim // num_heads, eps
         self.act_dtype = act_dtype
@@ -269,6 +269,7 @@ class WanAttentionBlockWithHipKernel(nn.Module):
         # quant_config.attn.v / cross_attn.v: v fake-quantised per (head, channel) over all tokens before the attention
         # (W/models/quant_opensora.py:438-440); P.V itself stays bf16 -- the reference's recipe has no integer P either
         self.attn_v_bits, self.cross_attn_v_bits = attn_v_bits, cross_attn_v_bits
+        self.attn_map, self.cross_attn_map = attn_map, cross_attn_map  # (n_bits, sym) of the attention-map quantiser, or None
         self.self_attn, self.cross_attn = _Attn(dim), _Attn(dim)
         self.ffn0 = self.ffn2 = None
         self.register_buffer("modulation", torch.zeros(1, 6, dim))
@@ -278,12 +279,12 @@ class WanAttentionBlockWithHipKernel(nn.Module):
 
     @classmethod
     def from_float(cls, blk, n_bits=8, sym=False, act_dtype=torch.bfloat16, attn_qk8=False, cross_attn_qk8=False,
-                   attn_v_bits=None, cross_attn_v_bits=None):
+                   attn_v_bits=None, cross_attn_v_bits=None, attn_map=None, cross_attn_map=None):
         """Build from a WanAttentionBlock (wan/modules/model.py) whose Linears are either plain nn.Linear
         (quantized here with plain per-channel W8 when n_bits is given, kept FP when n_bits is None) or qdiff
         QuantizedLinear variants (their codes / parameters / ViDiT transform are taken over as they are)."""
         m = cls(blk.dim, blk.ffn_dim, blk.num_heads, blk.eps, act_dtype, attn_qk8, cross_attn_qk8, attn_v_bits,
-                cross_attn_v_bits).to(blk.modulation.device)
+                cross_attn_v_bits, attn_map, cross_attn_map).to(blk.modulation.device)
         for name in ("self_attn", "cross_attn"):
             src, dst = getattr(blk, name), getattr(m, name)
             for l in "qkvo":
@@ -352,12 +353,17 @@ class WanAttentionBlockWithHipKernel(nn.Module):
             k = self._linear(sa.k, h)
             ops.rmsnorm_rope_(k, sa.norm_k_weight, rope, d, eps=self.eps)
             v = self._vq(self._linear(sa.v, h), self.attn_v_bits, seq_len)
-            o = ops.attention(q, k, v, H, seq_len)
+            if self.attn_map is not None:
+                o = ops.attention_map_quant(q, k, v, H, self.attn_map[0], self.attn_map[1], seq_len)
+            else:
+                o = ops.attention(q, k, v, H, seq_len)
         else:
             # Ulysses, pipelined over head chunks: this rank's H/P heads are split in two; the exchange of chunk 1 (and the
             # way back of chunk 0) flies under the attention of the other chunk, so about half of the all-to-all time of a
             # block hides behind its 2-6 ms of attention.  The collectives run in issue order on the group's own stream.
             # RMSNorm+RoPE writes q and k straight into the send images of the chunks ([P, Lp, w] each): no pack pass.
+            if self.attn_map is not None:
+                raise NotImplementedError("attn.attn_map under sequence parallelism is not implemented (single rank only)")
             lp, C = q.shape
             chunks = [(a * d, b * d) for a, b in _head_chunks(H // sp.size, lp * sp.size, q.device)]
             _, hmap, where = sp.packed_layout(lp, C, d, chunks, q.device)
@@ -392,7 +398,10 @@ class WanAttentionBlockWithHipKernel(nn.Module):
         else:
             ops.rmsnorm_rope_(q, ca.norm_q_weight, None, d, eps=self.eps)
             ops.rmsnorm_rope_(k, ca.norm_k_weight, None, d, eps=self.eps)
-            o = ops.attention(q, k, v, H)
+            if self.cross_attn_map is not None:
+                o = ops.attention_map_quant(q, k, v, H, self.cross_attn_map[0], self.cross_attn_map[1])
+            else:
+                o = ops.attention(q, k, v, H)
         self._linear(ca.o, _FpSrc(o), gate=self.ones_gate, residual=x)
 
         # ---- FFN: LN*(1+e4)+e3 -> GEMM -> GELU + quantise -> GEMM (+gate, +residual).  The GELU runs in ffn.2's quantiser when
