@@ -2,6 +2,9 @@
 """A/B timing of int8-GEMM kernel VARIANTS in one process (interleaved rounds, median / min): every shared library given on the
 command line (built from different revisions of csrc/gemm_w8a8.hip, e.g. into lib/variants/) is loaded with ctypes and its
 wanq_gemm_w8a8 / wanq_gemm_w4a8 are called on the same tensors; outputs must be BIT-EQUAL to the first library's.
+Bit-equality here is NOT a race screen: the residual-prefetch epilogue passed it while a missing workgroup barrier let the next
+tile's LDS-DMA overwrite other waves' residual buffers (waves run in lock-step in this harness); the full model caught it, and
+tests/test_gpu_gemm.py::test_fp32_gate_residual_in_place_many_tiles (short K, in place, repeated) now pins it.
 usage: ab_gemm_variants.py libA.so libB.so ...   (build: hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -shared csrc/gemm_w8a8.hip csrc/runtime.hip)"""
 import ctypes
 import sys
