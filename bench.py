@@ -249,7 +249,10 @@ def main():
     n_quant = sum(1 for m in model.modules() if isinstance(m, QuantizedLinear))
     n_w4 = sum(1 for b in model.hip_blocks for m in b.modules() if getattr(m, "w_bits", 8) == 4)
     hb0 = model.hip_blocks[0]
-    attn_desc = "bf16" if not (hb0.attn_qk8 or hb0.cross_attn_qk8 or hb0.attn_v_bits or hb0.cross_attn_v_bits) else ", ".join(
+    amaps = [(nm, am) for nm, am in (("self", getattr(hb0, "attn_map", None)), ("cross", getattr(hb0, "cross_attn_map", None))) if am]
+    attn_desc = "; ".join(f"{nm}: attention map {am[0]}-bit {'sym' if am[1] else 'asym'} per key column (three streamed passes, csrc/attn_map.hip)"
+                          for nm, am in amaps) + "; other attention bf16" if amaps else \
+        "bf16" if not (hb0.attn_qk8 or hb0.cross_attn_qk8 or hb0.attn_v_bits or hb0.cross_attn_v_bits) else ", ".join(
         [f"{nm}: " + " + ".join((["int8 Q.K^T (q, k per (token, head))"] if qk else []) + ([f"v {vb}-bit per (head, channel)"] if vb else []))
          for nm, qk, vb in (("self", hb0.attn_qk8, hb0.attn_v_bits), ("cross", hb0.cross_attn_qk8, hb0.cross_attn_v_bits)) if qk or vb]) + "; P.V bf16"
     sharded = None
