@@ -13,7 +13,7 @@
 //   pass 1  column maxima  c_k = max_q exp2(s - m_q) / l_q   -> workspace [H][Lk]   (atomic max on the bits of a float >= 0)
 //   pass 2  O = sum_k P~[q,k] V[k]                           (P~ rounded to bf16 for the P.V MFMA, fp32 accumulation)
 // A study feature (2.5x the attention work, and the reference cannot run it at all beyond toy lengths): written for
-// clarity, not tuned -- one wave per 16 queries, v_mfma_f32_16x16x32_bf16 with operands straight from global memory.
+// clarity, not tuned -- one wave per 32 queries, v_mfma_f32_16x16x32_bf16 with operands straight from global memory.
 #include "wanq_common.h"
 
 namespace wanq {
@@ -36,80 +36,95 @@ struct AttnMapParams {
   float* cmax;   // [H][Lk] column maxima of the normalised map
 };
 
-// One S^T block: keys kb .. kb+15 against the wave's 16 queries.  A = K rows (lane (r, g): row kb + r, d = 32 s + 8 g + [0, 8)),
-// B = Q fragments; accumulator element e of lane (n, g): key kb + 4 g + e, query n.  Keys >= Lk come out as -inf.
-__device__ __forceinline__ mf32x4 map_s_block(const AttnMapParams& p, const uint16_t* kbase, int kb, int r16, int g4, const mbf16x8 (&qf)[4]) {
-  int kr = kb + r16;
-  kr = kr < p.Lk ? kr : p.Lk - 1;
-  const uint16_t* kp = kbase + (int64_t)kr * p.k_stride + 8 * g4;
-  mf32x4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int sl = 0; sl < 4; ++sl) s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const mbf16x8*>(kp + 32 * sl), qf[sl], s, 0, 0, 0);
-#pragma unroll
-  for (int e = 0; e < 4; ++e)
-    if (kb + 4 * g4 + e >= p.Lk) s[e] = -INFINITY;
-  return s;
-}
-
+// One wave = 32 queries (two blocks nq of 16): a K fragment (and, in pass 2, a gathered V^T fragment) feeds the MFMAs of both.
 template <int PASS>
 __global__ __launch_bounds__(256) void attn_map_kernel(const AttnMapParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n16 = lane & 15, g4 = lane >> 4;
   const int head = blockIdx.y;
-  const int q0 = (blockIdx.x * 4 + wave) * 16;
+  const int q0 = (blockIdx.x * 4 + wave) * 32;
   if (q0 >= p.Lq) return;  // whole wave (no barriers in this kernel)
-  int qr = q0 + n16;
-  const bool q_ok = qr < p.Lq;
-  qr = q_ok ? qr : p.Lq - 1;
-
-  // Q fragments, pre-scaled by softmax scale * log2(e): query qr, d = 32 s + 8 g4 + [0, 8)
-  mbf16x8 qf[4];
-  {
-    const uint16_t* qp = p.q + (int64_t)qr * p.q_stride + head * 128 + 8 * g4;
+  int qr[2];
+  bool q_ok[2];
+  mbf16x8 qf[2][4];  // pre-scaled by softmax scale * log2(e): query qr[nq], d = 32 s + 8 g4 + [0, 8)
+#pragma unroll
+  for (int nq = 0; nq < 2; ++nq) {
+    qr[nq] = q0 + 16 * nq + n16;
+    q_ok[nq] = qr[nq] < p.Lq;
+    qr[nq] = q_ok[nq] ? qr[nq] : p.Lq - 1;
+    const uint16_t* qp = p.q + (int64_t)qr[nq] * p.q_stride + head * 128 + 8 * g4;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      qf[s] = *reinterpret_cast<const mbf16x8*>(qp + 32 * s);
+      qf[nq][s] = *reinterpret_cast<const mbf16x8*>(qp + 32 * s);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) qf[s][e] = (__bf16)((float)qf[s][e] * p.c);
+      for (int e = 0; e < 8; ++e) qf[nq][s][e] = (__bf16)((float)qf[nq][s][e] * p.c);
     }
   }
   const uint16_t* kbase = p.k + head * 128;
-  const int64_t stat = (int64_t)head * p.Lq + qr;
+  const int64_t stat[2] = {(int64_t)head * p.Lq + qr[0], (int64_t)head * p.Lq + qr[1]};
+
+  // S^T blocks of keys kb .. kb+15 against both query blocks: A = K rows (lane (r, g): row kb + r, d = 32 s + 8 g + [0, 8)),
+  // B = Q fragments; accumulator element e of lane (n, g): key kb + 4 g + e, query n.  Keys >= Lk come out as -inf.
+  auto s_blocks = [&](int kb, mf32x4 (&s)[2]) {
+    int kr = kb + n16;
+    kr = kr < p.Lk ? kr : p.Lk - 1;
+    const uint16_t* kp = kbase + (int64_t)kr * p.k_stride + 8 * g4;
+    s[0] = mf32x4{0.f, 0.f, 0.f, 0.f};
+    s[1] = mf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      const mbf16x8 kf = *reinterpret_cast<const mbf16x8*>(kp + 32 * sl);
+      s[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][sl], s[0], 0, 0, 0);
+      s[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][sl], s[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (kb + 4 * g4 + e >= p.Lk) { s[0][e] = -INFINITY; s[1][e] = -INFINITY; }
+  };
 
   if (PASS == 0) {
     // ---- row statistics.  The four lanes of a query (n, n+16, n+32, n+48) see different keys: the maximum is shared every
     // block, the partial sums are added at the end.
-    float m = -INFINITY, l = 0.f;
+    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
     for (int kb = 0; kb < p.Lk; kb += 16) {
-      const mf32x4 s = map_s_block(p, kbase, kb, n16, g4, qf);
-      float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mn = fmaxf(m, mx);  // finite from the first block on (its key 0 is never masked)
-      l = l * __builtin_amdgcn_exp2f(m - mn) + __builtin_amdgcn_exp2f(s[0] - mn) + __builtin_amdgcn_exp2f(s[1] - mn) +
-          __builtin_amdgcn_exp2f(s[2] - mn) + __builtin_amdgcn_exp2f(s[3] - mn);
-      m = mn;
+      mf32x4 s[2];
+      s_blocks(kb, s);
+#pragma unroll
+      for (int nq = 0; nq < 2; ++nq) {
+        float mx = fmaxf(fmaxf(s[nq][0], s[nq][1]), fmaxf(s[nq][2], s[nq][3]));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m[nq], mx);  // finite from the first block on (its key 0 is never masked)
+        l[nq] = l[nq] * __builtin_amdgcn_exp2f(m[nq] - mn) + __builtin_amdgcn_exp2f(s[nq][0] - mn) + __builtin_amdgcn_exp2f(s[nq][1] - mn) +
+                __builtin_amdgcn_exp2f(s[nq][2] - mn) + __builtin_amdgcn_exp2f(s[nq][3] - mn);
+        m[nq] = mn;
+      }
     }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    if (q_ok && g4 == 0) {
-      p.m[stat] = m;
-      p.l[stat] = l;
+#pragma unroll
+    for (int nq = 0; nq < 2; ++nq) {
+      float lt = l[nq];
+      lt += __shfl_xor(lt, 16, 64);
+      lt += __shfl_xor(lt, 32, 64);
+      if (q_ok[nq] && g4 == 0) {
+        p.m[stat[nq]] = m[nq];
+        p.l[stat[nq]] = lt;
+      }
     }
     return;
   }
 
-  const float m = p.m[stat], inv_l = 1.0f / p.l[stat];
+  const float m[2] = {p.m[stat[0]], p.m[stat[1]]}, inv_l[2] = {1.0f / p.l[stat[0]], 1.0f / p.l[stat[1]]};
 
   if (PASS == 1) {
-    // ---- column maxima of the normalised map: max over the wave's 16 queries (the 16 lanes of a lane group), then one atomic
-    // per key and wave.  Duplicated (clamped) queries of a ragged last block repeat a real query: harmless for a maximum.
+    // ---- column maxima of the normalised map: max over the wave's 32 queries (two blocks, then the 16 lanes of a lane group),
+    // then one atomic per key and wave.  Duplicated (clamped) queries of a ragged last block repeat a real query: harmless.
     unsigned int* cm = reinterpret_cast<unsigned int*>(p.cmax) + (int64_t)head * p.Lk;
     for (int kb = 0; kb < p.Lk; kb += 16) {
-      const mf32x4 s = map_s_block(p, kbase, kb, n16, g4, qf);
+      mf32x4 s[2];
+      s_blocks(kb, s);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float pv = __builtin_amdgcn_exp2f(s[e] - m) * inv_l;  // masked keys: exp2(-inf) = 0
+        float pv = fmaxf(__builtin_amdgcn_exp2f(s[0][e] - m[0]) * inv_l[0], __builtin_amdgcn_exp2f(s[1][e] - m[1]) * inv_l[1]);  // masked: 0
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) pv = fmaxf(pv, __shfl_xor(pv, o, 64));
         const int key = kb + 4 * g4 + e;
@@ -121,25 +136,32 @@ __global__ __launch_bounds__(256) void attn_map_kernel(const AttnMapParams p) {
 
   // ---- PASS 2: O^T += V^T . P~^T over key slices of 32 (two S blocks).  k index 8 g + j of the P.V MFMA <-> key
   // kb + 16 (j >> 2) + 4 g + (j & 3); the A operand V^T[d][that key] is gathered with 2-byte loads (d = 16 db + n16).
-  mf32x4 o[8];
+  mf32x4 o[8][2];
 #pragma unroll
-  for (int db = 0; db < 8; ++db) o[db] = mf32x4{0.f, 0.f, 0.f, 0.f};
+  for (int db = 0; db < 8; ++db) {
+    o[db][0] = mf32x4{0.f, 0.f, 0.f, 0.f};
+    o[db][1] = mf32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const float* cm = p.cmax + (int64_t)head * p.Lk;
   const uint16_t* vbase = p.v + head * 128 + n16;
   for (int kb = 0; kb < p.Lk; kb += 32) {
-    mbf16x8 pf;
+    mbf16x8 pf[2];
     int64_t vrow[8];
 #pragma unroll
     for (int jh = 0; jh < 2; ++jh) {
-      const mf32x4 s = map_s_block(p, kbase, kb + 16 * jh, n16, g4, qf);  // a block wholly past Lk gives -inf -> P~ = 0
+      mf32x4 s[2];
+      s_blocks(kb + 16 * jh, s);  // a block wholly past Lk gives -inf -> P~ = 0
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int key = kb + 16 * jh + 4 * g4 + e;
         const int kc = key < p.Lk ? key : p.Lk - 1;
         float delta = cm[kc] / p.levels;
         delta = delta < p.eps ? p.eps : delta;
-        const float pr = __builtin_amdgcn_exp2f(s[e] - m) * inv_l;
-        pf[4 * jh + e] = (__bf16)(__builtin_rintf(pr / delta) * delta);
+#pragma unroll
+        for (int nq = 0; nq < 2; ++nq) {
+          const float pr = __builtin_amdgcn_exp2f(s[nq][e] - m[nq]) * inv_l[nq];
+          pf[nq][4 * jh + e] = (__bf16)(__builtin_rintf(pr / delta) * delta);
+        }
         vrow[4 * jh + e] = (int64_t)kc * p.v_stride;
       }
     }
@@ -151,17 +173,20 @@ __global__ __launch_bounds__(256) void attn_map_kernel(const AttnMapParams p) {
         const uint16_t bits = vbase[vrow[j] + 16 * db];
         vf[j] = __builtin_bit_cast(__bf16, bits);
       }
-      o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[db], 0, 0, 0);
+      o[db][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0], o[db][0], 0, 0, 0);
+      o[db][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1], o[db][1], 0, 0, 0);
     }
   }
-  if (q_ok) {  // lane (n, g) holds O[query n][d = 16 db + 4 g + e]
-    uint16_t* op = p.o + (int64_t)qr * p.o_stride + head * 128 + 4 * g4;
+#pragma unroll
+  for (int nq = 0; nq < 2; ++nq) {
+    if (!q_ok[nq]) continue;  // lane (n, g) holds O[query n][d = 16 db + 4 g + e]
+    uint16_t* op = p.o + (int64_t)qr[nq] * p.o_stride + head * 128 + 4 * g4;
 #pragma unroll
     for (int db = 0; db < 8; ++db) {
       typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
       bf16x4 b;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) b[e] = (__bf16)o[db][e];
+      for (int e = 0; e < 4; ++e) b[e] = (__bf16)o[db][nq][e];
       *reinterpret_cast<bf16x4*>(op + 16 * db) = b;
     }
   }
@@ -209,7 +234,7 @@ extern "C" int wanq_attention_map_quant_fwd(const void* q, const void* k, const 
     set_error("%s: hipMemsetAsync failed", what);
     return WANQ_E_LAUNCH;
   }
-  dim3 grid((unsigned)((Lq + 63) / 64), (unsigned)heads);
+  dim3 grid((unsigned)((Lq + 127) / 128), (unsigned)heads);  // 4 waves x 32 queries
   hipLaunchKernelGGL(attn_map_kernel<0>, grid, dim3(256), 0, st, p);
   hipLaunchKernelGGL(attn_map_kernel<1>, grid, dim3(256), 0, st, p);
   hipLaunchKernelGGL(attn_map_kernel<2>, grid, dim3(256), 0, st, p);
