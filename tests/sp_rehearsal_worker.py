@@ -46,7 +46,8 @@ def main():
     ctx_u = torch.randn(24, 64, generator=g, device=dev) * 0.1
     t = torch.tensor([500], device=dev)
 
-    quant_config = qcfg.load(os.path.join(ROOT, "wan2.1-quantization_amd", "quant_configs", "w8a8_all_linears.yaml"))
+    # WANQ_REHEARSE_CONFIG: another file under quant_configs/ (e.g. the attention-map quantiser under sequence parallelism)
+    quant_config = qcfg.load(os.path.join(ROOT, "wan2.1-quantization_amd", "quant_configs", os.environ.get("WANQ_REHEARSE_CONFIG", "w8a8_all_linears.yaml")))
     model = QuantWanModel.from_float(fp, quant_config)
     model.quant_layer_refactor()
     hooks = calib.add_hooks(fp)

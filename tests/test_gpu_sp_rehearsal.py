@@ -39,6 +39,17 @@ def test_two_ranks_ulysses_at_14b_block_dims():
     assert r.stdout.count("fsdp_rel=0.000e+00") == 2, r.stdout[-2000:]
 
 
+def test_two_ranks_attention_map_quantiser_under_ulysses():
+    """attn.attn_map under Ulysses (sp 2): after the head exchange a rank holds all tokens of its heads, so the per-key-column
+    statistics over all queries are local -- bit-equal to the single-rank output."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(HERE, "sp_rehearsal_worker.py")]
+    env = dict(os.environ, OMP_NUM_THREADS="4", WANQ_REHEARSE_CONFIG="w8a8_all_linears_attn_map.yaml", WANQ_REHEARSE_NO_CFG_PARALLEL="1")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, f"attention-map rehearsal failed:\n{r.stdout[-4000:]}\n{r.stderr[-4000:]}"
+    assert r.stdout.count("sp_rel=0.000e+00") == 2, r.stdout[-2000:]
+
+
 @pytest.mark.parametrize("gpus,plan,extra", [(2, "cfg2xsp1", []), (4, "cfg2xsp2", []),
                                              (2, "cfg1xsp2", ["--no-cfg-parallel", "--dit-fsdp", "--quant-config", "w4a8_mixed.yaml"])])
 def test_bench_multi_rank_control_flow_rehearsal(gpus, plan, extra):

@@ -362,8 +362,6 @@ class WanAttentionBlockWithHipKernel(nn.Module):
             # way back of chunk 0) flies under the attention of the other chunk, so about half of the all-to-all time of a
             # block hides behind its 2-6 ms of attention.  The collectives run in issue order on the group's own stream.
             # RMSNorm+RoPE writes q and k straight into the send images of the chunks ([P, Lp, w] each): no pack pass.
-            if self.attn_map is not None:
-                raise NotImplementedError("attn.attn_map under sequence parallelism is not implemented (single rank only)")
             lp, C = q.shape
             chunks = [(a * d, b * d) for a, b in _head_chunks(H // sp.size, lp * sp.size, q.device)]
             _, hmap, where = sp.packed_layout(lp, C, d, chunks, q.device)
@@ -381,7 +379,13 @@ class WanAttentionBlockWithHipKernel(nn.Module):
             back = []
             for (c0, c1), (wq, wk, wv) in zip(chunks, pend):
                 # (v of this rank's heads, all tokens: the per-(head, channel) statistics are local after the exchange)
-                oc = ops.attention(wq.wait(), wk.wait(), self._vq(wv.wait(), self.attn_v_bits, seq_len), (c1 - c0) // d, seq_len)
+                # (after the exchange a rank holds ALL tokens of its heads: the attention-map quantiser's per-key-column statistics
+                # over all queries are local, like v's per-(head, channel) statistics)
+                qc, kc, vc = wq.wait(), wk.wait(), self._vq(wv.wait(), self.attn_v_bits, seq_len)
+                if self.attn_map is not None:
+                    oc = ops.attention_map_quant(qc, kc, vc, (c1 - c0) // d, self.attn_map[0], self.attn_map[1], seq_len)
+                else:
+                    oc = ops.attention(qc, kc, vc, (c1 - c0) // d, seq_len)
                 back.append(sp.gather_heads(oc, async_op=True, out=o, cols=(c0, c1)))
             for b in back:
                 b.wait()
