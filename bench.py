@@ -154,6 +154,23 @@ def cpu_baseline(cfg, L, n_vidit_per_block=3, rows=1024, reps=3):
                        "sample": f"one whole fake-quant block on all {La} tokens, median of {reps}: {t_blk:.3f}s, scaled x{cfg['num_layers']} blocks x2 passes"})
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: run `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N ... bench.py <same arguments>` as a CHILD process (never an exec: the parent stays a plain process
+    that has made no GPU call), pass its output through and return its exit status (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this image
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,6 +187,10 @@ def main():
     ap.add_argument("--graph", type=int, default=int(os.environ.get("WANQ_BENCH_GRAPH", "0")), choices=[0, 1],
                     help="1 (single GPU only): the two DiT passes of a step are replayed from a captured HIP graph "
                          "(wan/graph.py); 0 (default): every kernel is launched eagerly -- measured the same (DESIGN.md 5): the host runs ahead")
+    ap.add_argument("--no-context-cache", dest="no_context_cache", action="store_true",
+                    help="recompute cross_attn.k / cross_attn.v (+ RMSNorm) of the text context in every DiT pass, as round 2 did: they "
+                         "do not depend on the timestep, and by default they are computed once per context tensor and kept "
+                         "(QuantWanModel._context_source); the A/B of the two is in profiles/")
     ap.add_argument("--dit-fsdp", dest="dit_fsdp", action="store_true",
                     help="N > 1: shard the kernel-mode blocks' integer weights over all ranks, gathered one block ahead (wan/distributed/fsdp.py)")
     ap.add_argument("--preset", default=os.environ.get("WANQ_BENCH_PRESET", ""), choices=["", "14B-ulysses", "14B-w4a8-fsdp"],
@@ -182,10 +203,16 @@ def main():
     if args.preset == "14B-w4a8-fsdp":
         args.quant_config, args.dit_fsdp = "w4a8_mixed.yaml", True
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started the way the N = 1 run is started (`python bench.py --gpus N`): this process has not touched the GPU yet
+        # and never will -- it starts the N ranks as children, relays rank 0's JSON line and exits with their status
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (start it as `python bench.py --gpus N`, or under "
+                 f"torch.distributed.run with --nproc-per-node equal to --gpus)")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the quantized hot path has no CPU fallback)"
     # Rehearsal of the N > 1 control flow on a ONE-GPU box (RCCL refuses two ranks on one device): all ranks share cuda:0,
     # rendezvous over gloo, and the collectives are staged through host memory (wan/distributed/rehearsal.py).  Never a measurement.
@@ -246,6 +273,7 @@ def main():
         model.bitwidth_refactor()
     model.set_init_done()
     model.hardware_forward_refactor()
+    model.context_cache = not args.no_context_cache
     n_quant = sum(1 for m in model.modules() if isinstance(m, QuantizedLinear))
     n_w4 = sum(1 for b in model.hip_blocks for m in b.modules() if getattr(m, "w_bits", 8) == 4)
     hb0 = model.hip_blocks[0]
@@ -329,6 +357,8 @@ def main():
                                f"ViDiT-Q scale+rotate alpha=0.5665 on {n_vidit} self-attn q/k/v layers), "
                                f"{args.size}x{args.frames}f, latent {list(shape)}, L={seq_len}, cond+uncond+CFG+scheduler per step",
                    "quant_config": args.quant_config, "attention": attn_desc, "parallelism": plan.describe(),
+                   "context_kv": "cross_attn.k / .v of the text context computed once per context tensor (step-invariant), reused by every step"
+                                 if model.context_cache else "cross_attn.k / .v of the text context recomputed in every pass",
                    "dit_fsdp": None if sharded is None else {"ranks": sharded.P, "block_weight_MB_per_rank": round(sharded.bytes_per_rank() / 1e6, 1),
                                                              "of_MB": round(len(sharded.blocks) * sharded.full_bytes / 1e6, 1)},
                    "launch": "hip graph replay of the two DiT passes + 1 fused CFG/scheduler kernel" if graphed is not None else

@@ -75,8 +75,22 @@ def main():
     plan = ParallelPlan(world, rank, 1, world)
     assert plan.sp.size == world
     sl = seq_len_for(shape, sp_size=world)
+    if os.environ.get("WANQ_REHEARSE_EXPECT_QK8") == "1":
+        # the int8 Q.K^T kernel itself must run under sequence parallelism (one launch per head chunk and block), not the bf16 one
+        from wan import ops as wan_ops
+        calls = {"qk8": 0, "bf16": 0}
+        a8, a16 = wan_ops.attention_qk8, wan_ops.attention
+        wan_ops.attention_qk8 = lambda *a, **k: (calls.__setitem__("qk8", calls["qk8"] + 1), a8(*a, **k))[1]
+        wan_ops.attention = lambda *a, **k: (calls.__setitem__("bf16", calls["bf16"] + 1), a16(*a, **k))[1]
+        assert all(b.attn_qk8 for b in model.hip_blocks)
     out = model([latent], t, [ctx_c], sl, plan.sp)[0]
     e_sp = rel(out, ref_c)
+    if os.environ.get("WANQ_REHEARSE_EXPECT_QK8") == "1":
+        wan_ops.attention_qk8, wan_ops.attention = a8, a16
+        n_self = layers * len(qh._head_chunks(heads // world, 270, dev))
+        print(f"RANK {rank} qk8_launches_sp={calls['qk8']} bf16_launches_sp={calls['bf16']}", flush=True)
+        cross_q8 = all(b.cross_attn_qk8 for b in model.hip_blocks)
+        assert calls["qk8"] == n_self + (layers if cross_q8 else 0) and calls["bf16"] == (0 if cross_q8 else layers), calls
 
     def fsdp_leg():
         """--dit_fsdp on top of Ulysses: every block's integer weights live 1/P per rank and are gathered one block ahead."""

@@ -280,3 +280,49 @@ def _packed_worker(rank, world, port, q):
 
 def test_packed_send_images_equal_transpose_pack_world2():
     _run(_packed_worker, 2, 29691)
+
+
+def _q8_exchange_worker(rank, world, port, q):
+    """The int8 Q.K^T exchange of wan/quant_wanx_hip.py::_self_attention_qk8_ulysses in index form: per-(token, head) codes
+    and the two scale planes, quantised on the token shard, must arrive as exactly the head group's slice of what ONE rank
+    holding all tokens would have produced (codes, both planes, the 64-row zero padding of the key planes)."""
+    import traceback
+    try:
+        import torch
+        _init(rank, world, port)
+        from wan import ops
+        from wan.distributed.parallel import SeqParallel
+
+        sp = SeqParallel(None)
+        d, H, lp = 128, 2 * world, 7
+        L, C = lp * world, 2 * world * 128
+        g = torch.Generator().manual_seed(3)
+        codes_full = torch.randint(-127, 128, (L, C), generator=g, dtype=torch.int8)
+        delta_full = torch.rand(H, L, generator=g) + 0.01
+        planes_full = torch.stack([delta_full, -12582912.0 * delta_full])  # [2, H, L] as wanq_rmsnorm_rope_q8 writes them
+        # this rank's shard, in the Q8Rows layout of the producer (stride padded to 64 for keys)
+        loc = ops.Q8Rows.__new__(ops.Q8Rows)
+        loc.rows, loc.cols, loc.heads, loc.stride = lp, C, H, 64
+        loc.codes = codes_full[rank * lp:(rank + 1) * lp].contiguous()
+        loc.scales = torch.zeros(2, H, 64)
+        loc.scales[:, :, :lp] = planes_full[:, :, rank * lp:(rank + 1) * lp]
+        planes = loc.scales[:, :, :lp].permute(2, 1, 0).reshape(lp, 2 * H)
+        hp = H // world
+        for ch in ((0, d), (d, hp * d)):  # two head chunks of the rank's head group
+            cw = sp.scatter_heads(loc.codes, async_op=True, cols=ch)
+            pw = sp.scatter_heads(planes, async_op=True, cols=(2 * ch[0] // d, 2 * ch[1] // d))
+            for for_keys in (False, True):
+                got = ops.Q8Rows.from_exchange(cw.wait(), pw.wait(), d, for_keys)
+                h0, h1 = rank * hp + ch[0] // d, rank * hp + ch[1] // d
+                assert torch.equal(got.codes, codes_full[:, h0 * d:h1 * d])
+                assert got.stride == (64 if for_keys else L) and got.heads == h1 - h0
+                assert torch.equal(got.scales[:, :, :L], planes_full[:, h0:h1]) and not bool(got.scales[:, :, L:].any())
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        q.put((rank, traceback.format_exc()))
+
+
+def test_int8_qk_exchange_layout_world2():
+    _run(_q8_exchange_worker, 2, 29693)

@@ -273,6 +273,26 @@ def test_attention_map_quant_vs_oracle(Lq, Lk, H, klen, bits, sym):
     assert err.item() < (1.2e-2 if bits == 8 else 0.5 * noise.item() + 1e-2), (err.item(), noise.item())  # 4 bits: well inside the recipe's own noise
 
 
+def test_attention_map_quant_ignores_padded_query_rows():
+    """with a padded sequence (rows >= q_len are padding, e.g. the last rank's tail under Ulysses) a key column's
+    quantisation step must come from the REAL queries only, as in the reference, whose map has no padding rows.  The padded
+    rows here are built to dominate every column maximum if they were counted; with q_len the real rows are bit-equal to the
+    unpadded call and the padded output rows are zero."""
+    from wan import ops
+
+    d, H, Lq, pad, Lk = 128, 2, 83, 13, 150
+    g = torch.Generator().manual_seed(11)
+    q = (torch.randn(Lq + pad, H * d, generator=g) * 1.5).to(torch.bfloat16)
+    k = (torch.randn(Lk, H * d, generator=g) * 1.5).to(torch.bfloat16)
+    v = torch.randn(Lk, H * d, generator=g).to(torch.bfloat16)
+    q[Lq:] = (k[:pad].float() * 4.0).to(torch.bfloat16)  # padding rows that put ~all their mass on one key each
+    ref = ops.attention_map_quant(q[:Lq].contiguous().to(DEV), k.to(DEV), v.to(DEV), H, 8, False)
+    out = ops.attention_map_quant(q.to(DEV), k.to(DEV), v.to(DEV), H, 8, False, q_len=Lq)
+    assert torch.equal(out[:Lq], ref) and not bool(out[Lq:].any())
+    counted = ops.attention_map_quant(q.to(DEV), k.to(DEV), v.to(DEV), H, 8, False)  # padding counted: other steps, other rows
+    assert not torch.equal(counted[:Lq], ref)
+
+
 def test_attention_map_quant_matches_reference_golden(golden=None):
     """The same entry point on the inputs of the reference-generated fixture (q, k, v as bf16): against the reference's own
     `attn_quantised @ v`."""

@@ -390,3 +390,93 @@ def test_reference_format_checkpoint_layout_and_reload(tmp_path):
     err = rel_err(out.cpu(), ref.cpu())
     print(f"kernel mode from the reference-format checkpoint vs from the in-memory layers: {err:.2e}")
     assert 0 < err < 5e-3  # fp16 scales / biases: not bit-equal, and not far
+
+
+def _tiny_kernel_mode_model(raw_cfg, seed=0, dim=256, ffn=512, heads=2, layers=2):
+    from qdiff import config as qcfg
+    from wan.modules.model import WanModel
+    from wan.quant_wanx import QuantWanModel
+
+    quant_config = qcfg.create(raw_cfg)
+    torch.manual_seed(seed)
+    with torch.device(DEV):
+        fp = WanModel(dim=dim, ffn_dim=ffn, num_heads=heads, num_layers=layers, text_dim=64, freq_dim=64).eval()
+    g = torch.Generator(device=DEV).manual_seed(seed + 2)
+    torch.nn.init.xavier_uniform_(fp.head.head.weight, generator=g)
+    for m in fp.modules():
+        if isinstance(m, torch.nn.Linear) and m.bias is not None:
+            m.bias.data.normal_(std=0.02, generator=g)
+    model = QuantWanModel.from_float(fp, quant_config)
+    model.quant_layer_refactor()
+    model.set_init_done()
+    return model
+
+
+def test_reference_format_roundtrip_with_symmetric_weights(tmp_path):
+    """the reference's checkpoint format carries a `zp_weight` for every layer (all zeros when the weight quantiser
+    is symmetric); the kernel-mode loader must take such a file back -- save(reference_format=True) -> load -> same output up to
+    the fp16 rounding of the scales -- and must still refuse a NON-zero zero point for a layer that has none."""
+    from wan.configs import seq_len_for
+
+    model = _tiny_kernel_mode_model({"weight": {"n_bits": 8, "sym": True}, "act": {"n_bits": 8, "sym": True}, "remain_fp_regex": "head"})
+    path = str(tmp_path / "int_weight.pt")
+    sd = model.quantize_and_save_weight(path, reference_format=True)
+    zp = sd["blocks.0.self_attn.q.zp_weight"]
+    assert zp.dtype == torch.float16 and not bool(zp.any())
+    shape = (16, 2, 8, 6)
+    gl = torch.Generator(device=DEV).manual_seed(3)
+    latent, ctx, t = torch.randn(shape, generator=gl, device=DEV), torch.randn(16, 64, generator=gl, device=DEV) * 0.1, torch.tensor([500], device=DEV)
+    model.hardware_forward_refactor()
+    assert model.hip_blocks[0].self_attn.q.zp_weight is None
+    ref = model([latent], t, [ctx], seq_len_for(shape))[0].float()
+    model.hardware_forward_refactor(path)
+    out = model([latent], t, [ctx], seq_len_for(shape))[0].float()
+    err = rel_err(out.cpu(), ref.cpu())
+    print(f"symmetric-weight reference-format round trip: {err:.2e}")
+    assert 0 < err < 5e-3
+    bad = dict(sd)
+    bad["blocks.0.self_attn.q.zp_weight"] = zp + 1
+    torch.save(bad, path)
+    with pytest.raises(KeyError):
+        model.hardware_forward_refactor(path)
+
+
+def test_context_kv_cache_is_bit_equal_and_follows_the_context_tensor():
+    """cross_attn.k (+ RMSNorm) / cross_attn.v of the text context are step-invariant (W/wan/modules/model.py:178-200) and are
+    kept per live context tensor across forward calls: same bits as recomputing them, fewer GEMM launches, recomputed for
+    another tensor and after an in-place write to the same one."""
+    from viditq_extension import qgemm
+    from wan.configs import seq_len_for
+
+    model = _tiny_kernel_mode_model({"weight": {"n_bits": 8, "sym": False}, "act": {"n_bits": 8, "sym": True}, "remain_fp_regex": "head"})
+    model.hardware_forward_refactor()
+    shape = (16, 2, 8, 6)
+    gl = torch.Generator(device=DEV).manual_seed(5)
+    latent, t = torch.randn(shape, generator=gl, device=DEV), torch.tensor([500], device=DEV)
+    ctx_a, ctx_b = (torch.randn(16, 64, generator=gl, device=DEV) * 0.1 for _ in range(2))
+    sl = seq_len_for(shape)
+
+    def run(ctx):
+        tm = []
+        qgemm.set_timer(tm)
+        try:
+            y = model([latent], t, [ctx], sl)[0]
+        finally:
+            qgemm.set_timer(None)
+        return y, len(tm)
+
+    model.context_cache = False
+    ya, n_off = run(ctx_a)
+    yb, _ = run(ctx_b)
+    model.context_cache = True
+    y1, n_first = run(ctx_a)
+    y2, n_again = run(ctx_a)
+    y3, n_other = run(ctx_b)
+    assert torch.equal(y1, ya) and torch.equal(y2, ya) and torch.equal(y3, yb)
+    nb = len(model.hip_blocks)
+    assert n_first == n_off and n_other == n_off and n_again == n_off - 2 * nb  # k and v GEMMs of every block gone
+    ctx_a.mul_(2.0)  # in-place write: the version counter moves and the entry is recomputed
+    y4, n_written = run(ctx_a)
+    model.context_cache = False
+    y4_ref, _ = run(ctx_a)
+    assert n_written == n_off and torch.equal(y4, y4_ref) and not torch.equal(y4, ya)

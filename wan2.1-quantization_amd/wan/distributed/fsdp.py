@@ -10,8 +10,11 @@ few KB per layer and stay replicated):
     padded to a multiple of P, and each rank keeps its 1/P slice (`shard`);
   * two full-size byte buffers exist per rank; before block i runs, its slices are all-gathered into buffer i % 2 and the
     block's weight tensors are re-pointed at views of that buffer; the all-gather of block i+1 is issued BEFORE block i's
-    compute, on a side stream, so that it flies under the block's 10+ ms of GEMMs and attention (RCCL runs it on the process
-    group's own stream; `wait()` only makes the compute stream wait for it);
+    compute, on a side stream and on a process group OF ITS OWN (`gather_group`: same ranks as `group`, separate RCCL
+    communicator).  ProcessGroupNCCL runs all collectives of one group on one internal stream in issue order, so on the group
+    the Ulysses exchange uses, block i's q / k / v all-to-alls would queue behind the 0.35-GB gather issued just before them;
+    with its own communicator the gather can fly under the block's 10+ ms of GEMMs and attention (`wait()` only makes the
+    compute stream wait for it).  Not yet timed on real multi-rank RCCL (no multi-GPU box from this container);
   * per rank memory for the blocks: total / P + 2 blocks (14B W8: 14 GB -> 1.75 GB + 0.7 GB at P = 8).
 
 Backend agnostic (plain torch.distributed): tested under gloo with world_size 2 on CPU tensors, rehearsed on the one-GPU box."""
@@ -35,10 +38,15 @@ def _weight_slots(block):
 
 
 class ShardedBlocks:
-    def __init__(self, blocks, group=None, slots_fn=_weight_slots):
+    def __init__(self, blocks, group=None, slots_fn=_weight_slots, gather_group=None):
         self.blocks, self.group, self.slots_fn = list(blocks), group, slots_fn
         self.P = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.P > 1 else 0
+        # a communicator of its own for the weight gathers (collective call: every rank of the default group builds its
+        # ShardedBlocks at the same point, as bench.py / quant_generate.py do); ranks and rank order are those of `group`
+        if gather_group is None and self.P > 1:
+            gather_group = dist.new_group(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD))
+        self.gather_group = gather_group if self.P > 1 else group
         first = slots_fn(self.blocks[0])
         self.layout = []  # (byte offset, nbytes, shape, dtype) per slot
         off = 0
@@ -82,9 +90,9 @@ class ShardedBlocks:
             # the buffer was last read by block i-2: the side stream must not overwrite it before that block's kernels are done
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
-                self._pending[i] = dist.all_gather_into_tensor(buf, self.shards[i], group=self.group, async_op=True)
+                self._pending[i] = dist.all_gather_into_tensor(buf, self.shards[i], group=self.gather_group, async_op=True)
         else:
-            self._pending[i] = dist.all_gather_into_tensor(buf, self.shards[i], group=self.group, async_op=True)
+            self._pending[i] = dist.all_gather_into_tensor(buf, self.shards[i], group=self.gather_group, async_op=True)
 
     def materialize(self, i):
         """Block i's weight tensors become views of the gathered buffer (waits for the gather; starts the next one)."""

@@ -69,6 +69,20 @@ class Q8Rows:
         self.codes = torch.empty(rows, cols, dtype=torch.int8, device=device)
         self.scales = torch.zeros(2, self.heads, self.stride, dtype=torch.float32, device=device)
 
+    @classmethod
+    def from_exchange(cls, codes, planes, head_dim, for_keys):
+        """After the Ulysses head exchange: codes int8 [L, w] (this rank's heads, all tokens) and the token-major scale pairs
+        [L, heads * 2] that travelled with them -> the [2, heads, stride] planes the attention kernel reads (key planes padded to
+        a multiple of 64 rows with zeros, as wanq_rmsnorm_rope_q8 leaves them)."""
+        L, w = codes.shape
+        self = cls.__new__(cls)
+        self.rows, self.cols, self.heads = L, w, w // head_dim
+        self.stride = -(-L // 64) * 64 if for_keys else L
+        self.codes = codes
+        self.scales = torch.zeros(2, self.heads, self.stride, dtype=torch.float32, device=codes.device)
+        self.scales[:, :, :L] = planes.view(L, self.heads, 2).permute(2, 1, 0)
+        return self
+
 
 def rmsnorm_rope_q8(x, weight, rope, head_dim, for_keys, eps=1e-6, want_fp=False):
     """RMSNorm_C(x) * weight -> rotary -> per-(token, head) int8 quantise: returns Q8Rows (and the bf16 row when want_fp).
@@ -126,10 +140,20 @@ def attention_qk8(q8, k8, v, num_heads, k_len=None, out=None, splits=None):
     return out
 
 
-def attention_map_quant(q, k, v, num_heads, n_bits=8, sym=False, k_len=None, out=None):
+def attention_map_quant(q, k, v, num_heads, n_bits=8, sym=False, k_len=None, out=None, q_len=None):
     """softmax(q k^T / sqrt(d)) with every KEY column of the map fake-quantised over all queries, then @ v -- the reference's
     `attn.attn_map` recipe, group 'row' (Q/base/quant_attn.py:118-173), streamed in three passes (csrc/attn_map.hip).
-    q [Lq, C], k / v [Lk, C] bf16 -> [Lq, C]."""
+    q [Lq, C], k / v [Lk, C] bf16 -> [Lq, C].  q_len: number of REAL query rows (the rest is sequence padding): a column's
+    quantisation step is taken over the real queries only, as the reference's map holds no padding rows; padded output rows
+    are zero."""
+    if q_len is not None and int(q_len) < q.shape[0]:
+        n = int(q_len)
+        if out is None:
+            out = torch.empty(q.shape[0], q.shape[1], dtype=q.dtype, device=q.device)
+        out[n:].zero_()
+        if n > 0:
+            attention_map_quant(q[:n], k, v, num_heads, n_bits, sym, k_len, out[:n])
+        return out
     Lq, C = q.shape
     d = C // num_heads
     for n, t in (("q", q), ("k", k), ("v", v)):

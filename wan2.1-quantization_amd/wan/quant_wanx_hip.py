@@ -199,6 +199,9 @@ class _FpSrc:
 
     def __init__(self, t, fp_dtype=None, gelu=False):
         self.t, self.cache, self.fp_dtype, self.gelu = t, {}, fp_dtype, gelu
+        # `derived`: what consumers computed from this source and may reuse while the source lives (the text context is the same
+        # tensor in every denoising step: a block's cross-attention k / v of it are kept here, keyed by the block)
+        self.derived = None
 
     def int8(self, lin):
         key = lin.act_key
@@ -329,6 +332,66 @@ class WanAttentionBlockWithHipKernel(nn.Module):
             fused.fake_quant_cols_(v if k_len is None or k_len >= v.shape[0] else v[:k_len], n_bits)
         return v
 
+    def _context_kv(self, ctx):
+        """Cross-attention k (after its RMSNorm; Q8Rows under cross_attn.qk) and v (after cross_attn.v's fake-quant) of the text
+        context.  Neither depends on the timestep or on the latent (W/wan/modules/model.py:178-200: k = norm_k(k(context)),
+        v = v(context)), and the sampling loop hands every step the same context tensor (W/wan/text2video.py:248-269), so a
+        source that carries a `derived` dict (QuantWanModel.forward keeps one per live context tensor) gets them computed once
+        per block and reused: 2 GEMMs + 1-2 rowwise launches per block and pass leave the step, bit-identical results."""
+        memo = ctx.derived
+        if memo is not None and id(self) in memo:
+            return memo[id(self)]
+        ca, d = self.cross_attn, self.head_dim
+        k = self._linear(ca.k, ctx)
+        v = self._vq(self._linear(ca.v, ctx), self.cross_attn_v_bits, None)
+        if self.cross_attn_qk8:
+            k = ops.rmsnorm_rope_q8(k, ca.norm_k_weight, None, d, True, eps=self.eps)
+        else:
+            ops.rmsnorm_rope_(k, ca.norm_k_weight, None, d, eps=self.eps)
+        if memo is not None:
+            memo[id(self)] = (k, v)
+        return k, v
+
+    def _self_attention_qk8_ulysses(self, q, h, rope, seq_len, sp):
+        """attn.qk under Ulysses.  The q / k quantiser works on (token, head) rows (Q/base/quant_attn.py:168-174 on the reshape of
+        W/models/quant_opensora.py:431-436), and a rank holds whole (token, head) rows on BOTH sides of the head exchange -- so
+        the rows are quantised where RMSNorm + RoPE produces them (same kernel, same codes as on one GPU) and the all-to-all moves
+        the int8 codes and the two fp32 scale planes: half the xGMI bytes of the bf16 exchange, bit-equal to the single-rank
+        result.  Pipelined over head chunks like the bf16 path (chunk 0 of q under the k GEMM, of k under the v GEMM, the rest
+        and the way back under the attention of the previous chunk)."""
+        sa, d, P = self.self_attn, self.head_dim, sp.size
+        lp, C = q.shape
+        H = C // d
+        chunks = [(a * d, b * d) for a, b in _head_chunks(H // P, lp * P, q.device)]
+
+        def token_major(s8):  # scale planes [2, H, stride] -> [lp, H * 2]: a head's (delta, constant) pair travels with its codes
+            return s8.scales[:, :, :lp].permute(2, 1, 0).reshape(lp, 2 * H)
+
+        def send(s8, planes, ch):
+            return (sp.scatter_heads(s8.codes, async_op=True, cols=ch),
+                    sp.scatter_heads(planes, async_op=True, cols=(2 * ch[0] // d, 2 * ch[1] // d)))
+
+        q8 = ops.rmsnorm_rope_q8(q, sa.norm_q_weight, rope, d, False, eps=self.eps)
+        qp = token_major(q8)
+        pend = [[send(q8, qp, chunks[0])]]
+        k8 = ops.rmsnorm_rope_q8(self._linear(sa.k, h), sa.norm_k_weight, rope, d, True, eps=self.eps)
+        kp = token_major(k8)
+        pend[0].append(send(k8, kp, chunks[0]))
+        v = self._linear(sa.v, h)
+        pend[0].append(sp.scatter_heads(v, async_op=True, cols=chunks[0]))
+        for ch in chunks[1:]:
+            pend.append([send(q8, qp, ch), send(k8, kp, ch), sp.scatter_heads(v, async_op=True, cols=ch)])
+        o = torch.empty(lp, C, dtype=self.act_dtype, device=q.device)
+        back = []
+        for (c0, c1), (wq, wk, wv) in zip(chunks, pend):
+            qc = ops.Q8Rows.from_exchange(wq[0].wait(), wq[1].wait(), d, False)
+            kc = ops.Q8Rows.from_exchange(wk[0].wait(), wk[1].wait(), d, True)
+            vc = self._vq(wv.wait(), self.attn_v_bits, seq_len)
+            back.append(sp.gather_heads(ops.attention_qk8(qc, kc, vc, (c1 - c0) // d, seq_len), async_op=True, out=o, cols=(c0, c1)))
+        for b in back:
+            b.wait()
+        return o
+
     def forward(self, x, e0, rope, seq_len, ctx, sp=None):
         """x: fp32 [L, C] residual stream (this rank's token shard under sequence parallelism), updated IN PLACE.
         e0: fp32 [1, 6, C].  rope: fp32 [pos, d/2, 2] for the local tokens.  seq_len: number of real (unpadded)
@@ -342,8 +405,9 @@ class WanAttentionBlockWithHipKernel(nn.Module):
         h = _LnSrc(self, x, None, e[:, 0], e[:, 1])
         h.prefetch([sa.q, sa.k, sa.v])  # one pass over x for the three ViDiT-transformed int8 inputs
         q = self._linear(sa.q, h)
-        if self.attn_qk8 and (sp is None or sp.size == 1):
-            # (under sequence parallelism the exchange moves bf16 q / k; the int8 form is single-rank for now)
+        if self.attn_qk8 and sp is not None and sp.size > 1:
+            o = self._self_attention_qk8_ulysses(q, h, rope, seq_len, sp)
+        elif self.attn_qk8:
             q8 = ops.rmsnorm_rope_q8(q, sa.norm_q_weight, rope, d, False, eps=self.eps)
             k8 = ops.rmsnorm_rope_q8(self._linear(sa.k, h), sa.norm_k_weight, rope, d, True, eps=self.eps)
             v = self._vq(self._linear(sa.v, h), self.attn_v_bits, seq_len)
@@ -354,7 +418,7 @@ class WanAttentionBlockWithHipKernel(nn.Module):
             ops.rmsnorm_rope_(k, sa.norm_k_weight, rope, d, eps=self.eps)
             v = self._vq(self._linear(sa.v, h), self.attn_v_bits, seq_len)
             if self.attn_map is not None:
-                o = ops.attention_map_quant(q, k, v, H, self.attn_map[0], self.attn_map[1], seq_len)
+                o = ops.attention_map_quant(q, k, v, H, self.attn_map[0], self.attn_map[1], seq_len, q_len=seq_len)
             else:
                 o = ops.attention(q, k, v, H, seq_len)
         else:
@@ -383,7 +447,7 @@ class WanAttentionBlockWithHipKernel(nn.Module):
                 # over all queries are local, like v's per-(head, channel) statistics)
                 qc, kc, vc = wq.wait(), wk.wait(), self._vq(wv.wait(), self.attn_v_bits, seq_len)
                 if self.attn_map is not None:
-                    oc = ops.attention_map_quant(qc, kc, vc, (c1 - c0) // d, self.attn_map[0], self.attn_map[1], seq_len)
+                    oc = ops.attention_map_quant(qc, kc, vc, (c1 - c0) // d, self.attn_map[0], self.attn_map[1], seq_len, q_len=seq_len)
                 else:
                     oc = ops.attention(qc, kc, vc, (c1 - c0) // d, seq_len)
                 back.append(sp.gather_heads(oc, async_op=True, out=o, cols=(c0, c1)))
@@ -394,16 +458,18 @@ class WanAttentionBlockWithHipKernel(nn.Module):
         # ---- cross attention: LN_affine -> q; k,v from the text context
         h = _LnSrc(self, x, self.norm3_weight, self.norm3_bias.view(1, -1), None)
         q = self._linear(ca.q, h)
-        k = self._linear(ca.k, ctx)
-        v = self._vq(self._linear(ca.v, ctx), self.cross_attn_v_bits, None)
+        k, v = self._context_kv(ctx)
         if self.cross_attn_qk8:
-            o = ops.attention_qk8(ops.rmsnorm_rope_q8(q, ca.norm_q_weight, None, d, False, eps=self.eps),
-                                  ops.rmsnorm_rope_q8(k, ca.norm_k_weight, None, d, True, eps=self.eps), v, H)
+            o = ops.attention_qk8(ops.rmsnorm_rope_q8(q, ca.norm_q_weight, None, d, False, eps=self.eps), k, v, H)
         else:
             ops.rmsnorm_rope_(q, ca.norm_q_weight, None, d, eps=self.eps)
-            ops.rmsnorm_rope_(k, ca.norm_k_weight, None, d, eps=self.eps)
             if self.cross_attn_map is not None:
-                o = ops.attention_map_quant(q, k, v, H, self.cross_attn_map[0], self.cross_attn_map[1])
+                if sp is not None and sp.size > 1:
+                    # a rank's queries are a token shard here (the cross-attention is not exchanged), so a key column's maximum
+                    # over ALL queries would need a MAX all-reduce between the passes: not built -- refuse rather than quantise
+                    # per shard and give N > 1 other numerics than N = 1
+                    raise NotImplementedError("cross_attn.attn_map under sequence parallelism (column statistics span the ranks' token shards)")
+                o = ops.attention_map_quant(q, k, v, H, self.cross_attn_map[0], self.cross_attn_map[1], q_len=seq_len)
             else:
                 o = ops.attention(q, k, v, H)
         self._linear(ca.o, _FpSrc(o), gate=self.ones_gate, residual=x)

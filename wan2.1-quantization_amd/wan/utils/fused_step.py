@@ -5,8 +5,11 @@ Every operation of the UniPC / DPM++ / Euler update is `tensor +- tensor` or `sc
 linear combination of a handful of latent-sized tensors: the current sample, the two model outputs and the scheduler's own
 history.  FusedStep runs the scheduler's UNCHANGED step() on symbolic linear forms (LinForm: a float64 coefficient vector over
 those tensors) to get the coefficients, and evaluates all results of the step -- next sample, the new history entries -- with
-ONE launch of wanq_lincomb.  The coefficient table lives in device memory and is refreshed by an async copy, so the launch can
-be replayed from a captured HIP graph."""
+ONE launch of wanq_lincomb.  The (at most 32) coefficients of a step travel BY VALUE in the kernel arguments of that launch:
+a coefficient table in device memory refreshed by an async copy per step raced as soon as the CPU ran a step ahead of the GPU
+(the next step's copy overwrote the table under the previous launch; csrc/stepops.hip header, regression test
+test_fused_step_with_the_cpu_running_steps_ahead_of_the_gpu).  The launch therefore cannot be replayed from a captured HIP
+graph with changing coefficients: the scheduler update stays OUTSIDE the captured DiT passes (wan/graph.py)."""
 import numpy as np
 import torch
 
