@@ -643,8 +643,40 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnParams p) {
 // the 32x32 kernel is 2-way for them); the V image is the one above.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// The tile is bound by the SIMD's vector ISSUE port, not by the matrix pipe: a 16x16x32 MFMA holds the port for 8 of its 16
+// cycles, and the two waves of a SIMD share it -- per wave and 64-key tile 64 MFMAs (512 issue cycles) + 32 v_exp (256) + the
+// softmax bookkeeping.  Two pieces of that bookkeeping are therefore moved / shortened (round 3):
+//   WANQ_ATTN_LSUM_MFMA  the row sums l = sum_k P are accumulated ON THE MATRIX CORES: one MFMA per (key slice, query block)
+//                        with an all-ones A operand and the same B operand (P as bf16) as the P.V MFMAs -- 4 MFMAs (32 issue
+//                        cycles) replace 32 dependent v_add_f32 (128) and the s_nop hipcc puts between a v_exp and the add that
+//                        consumes it (16 per tile).  Every row of the 16x16 result is the row sum, so every lane holds its
+//                        query's total (no cross-lane reduction in the epilogue), and l now sums exactly the bf16-rounded P
+//                        that P.V uses.
+//   WANQ_ATTN_MAX3       the lazy-rescale vote needs the maximum of the lane's 32 scores: 16 v_max3_f32 written as asm (the
+//                        builtin form costs 21: hipcc canonicalises MFMA outputs with v_max_f32 x, x first).
+#ifndef WANQ_ATTN_LSUM_MFMA
+#define WANQ_ATTN_LSUM_MFMA 1
+#endif
+#ifndef WANQ_ATTN_MAX3
+#define WANQ_ATTN_MAX3 0
+#endif
+#ifndef WANQ_ATTN_KASM
+#define WANQ_ATTN_KASM 4
+#endif
+#ifndef WANQ_ATTN_DMA_LATE
+#define WANQ_ATTN_DMA_LATE 0
+#endif
+// timing-only ablations (wrong results; tools/probes/README.md): skip the lazy-rescale vote after the first tile / replace v_exp
+#ifndef WANQ_ABL_NOMAX
+#define WANQ_ABL_NOMAX 0
+#endif
+#ifndef WANQ_ABL_NOEXP
+#define WANQ_ABL_NOEXP 0
+#endif
+
 template <bool SPLIT, bool QK8>
 __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) {
+  constexpr bool LSUM = WANQ_ATTN_LSUM_MFMA != 0 && !(SPLIT && !QK8);  // (the bf16 split-KV form has no 8 registers to spare: it spills)
   constexpr int STAGE = QK8 ? AT_STAGE8 : AT_STAGE;
   constexpr int VOFF = QK8 ? AT_K8 : AT_TILE;  // byte offset of the V tile inside a stage
   typedef int v4i __attribute__((ext_vector_type(4)));
@@ -782,6 +814,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[i][nq][r] = 0.f;
   float m_run[2] = {QK8 ? -INFINITY : 0.f, QK8 ? -INFINITY : 0.f}, l_run[2] = {0.f, 0.f};
+  f32x4 lacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // LSUM: row sums as MFMA accumulators (all four elements equal)
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  asm volatile("" : "+v"(ones));  // one register quad for the whole kernel, not rematerialised per use
   f32x4 sinit[2];
 #pragma unroll
   for (int nq = 0; nq < 2; ++nq)
@@ -813,11 +850,40 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
     if (j >= jt1) break;
     const char* sK = smem + u * STAGE;
     asm volatile("" : "+v"(d_k0), "+v"(d_k1), "+v"(d_k2), "+v"(d_k3), "+v"(d_v0), "+v"(d_v1), "+v"(d_v2), "+v"(d_v3));
-    if (j + 2 < jt1) A16_DMA(j + 2, (u + 2) % 3);
+    if (!((WANQ_ATTN_DMA_LATE != 0) && (WANQ_ATTN_KASM != 0) && !QK8) && j + 2 < jt1) A16_DMA(j + 2, (u + 2) % 3);
 
     // ---------------- S^T blocks: fragment i = 4 kb + s read four ahead of its two MFMAs
     f32x4 sacc[4][2];
-    if (!QK8) {
+    if (!QK8 && WANQ_ATTN_KASM) {
+      // K fragments by asm reads with COUNTED waits: fragment i is waited for with the KA-1 younger reads still in flight
+      // (hipcc merges the waits of the builtin form into three s_waitcnt lgkmcnt(0) per tile, each of which drains the
+      // lookahead it was given)
+      constexpr int KA = WANQ_ATTN_KASM;  // fragments in flight
+      bf16x8 kf[16];
+      const uint32_t kbase = lds_base + u * STAGE;
+      const uint32_t ka0 = kbase + koff0, ka1 = kbase + koff1, ka2 = kbase + koff2, ka3 = kbase + koff3;
+#define A16_KR(i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[i]) : "v"(((i) & 3) == 0 ? ka0 : ((i) & 3) == 1 ? ka1 : ((i) & 3) == 2 ? ka2 : ka3), "n"(((i) >> 2) * 4096))
+#pragma unroll
+      for (int i = 0; i < KA; ++i) { A16_KR(i); }
+      if (WANQ_ATTN_DMA_LATE && j + 2 < jt1) A16_DMA(j + 2, (u + 2) % 3);  // the first fragments fly under the DMA issue
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i + KA < 16) { A16_KR(i + KA); }
+        const int left = 15 - i < KA ? 15 - i : KA;  // reads younger than fragment i
+        if (left >= 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(kf[i]));
+        else if (left == 5) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(kf[i]));
+        else if (left == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(kf[i]));
+        else if (left == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(kf[i]));
+        else if (left == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(kf[i]));
+        else if (left == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(kf[i]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[i]));
+        __builtin_amdgcn_sched_barrier(0);
+        const int kb = i >> 2, s = i & 3;
+        sacc[kb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i], qf[0][QK8 ? 0 : s], s == 0 ? sinit[0] : sacc[kb][0], 0, 0, 0);
+        sacc[kb][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i], qf[QK8 ? 0 : 1][QK8 ? 0 : s], s == 0 ? sinit[1] : sacc[kb][1], 0, 0, 0);
+      }
+#undef A16_KR
+    } else if (!QK8) {
       bf16x8 kf[16];
 #define A16_KF(i) kf[i] = *reinterpret_cast<const bf16x8*>(sK + (((i) & 3) == 0 ? koff0 : ((i) & 3) == 1 ? koff1 : ((i) & 3) == 2 ? koff2 : koff3) + ((i) >> 2) * 4096)
       A16_KF(0); A16_KF(1); A16_KF(2); A16_KF(3);
@@ -872,11 +938,29 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
     }
 
     // ---------------- online softmax: lane-local maxima, cross-lane only when the reference moves
-    float mx0 = sacc[0][0][0], mx1 = sacc[0][1][0];
+    // lane-local maxima of the tile's scores for the lazy-rescale vote.  MAX3: two asm statements of eight v_max3_f32 (one
+    // statement per chain: hipcc pads every asm statement with an s_nop, and canonicalises the inputs of a builtin fmaxf);
+    // in the bf16 form mx1 then covers BOTH query blocks (the vote needs nothing finer; the rare branch recomputes block 1's)
+    float mx0, mx1;
+    if (WANQ_ATTN_MAX3) {
+#define A16_M8(dst, seed, b)                                                                                                    \
+  asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max3_f32 %0, %0, %8, %9\n\t"    \
+      "v_max3_f32 %0, %0, %10, %11\n\tv_max3_f32 %0, %0, %12, %13\n\tv_max3_f32 %0, %0, %14, %15\n\tv_max3_f32 %0, %0, %16, %17" \
+      : "=&v"(dst)                                                                                                              \
+      : "v"(seed), "v"(sacc[0][b][0]), "v"(sacc[0][b][1]), "v"(sacc[0][b][2]), "v"(sacc[0][b][3]), "v"(sacc[1][b][0]),          \
+        "v"(sacc[1][b][1]), "v"(sacc[1][b][2]), "v"(sacc[1][b][3]), "v"(sacc[2][b][0]), "v"(sacc[2][b][1]), "v"(sacc[2][b][2]), \
+        "v"(sacc[2][b][3]), "v"(sacc[3][b][0]), "v"(sacc[3][b][1]), "v"(sacc[3][b][2]), "v"(sacc[3][b][3]))
+      A16_M8(mx0, sacc[0][0][0], 0);  // (the seed repeats a score of the chain)
+      if (QK8) { A16_M8(mx1, sacc[0][1][0], 1); }  // int8 form: the two blocks' scores carry different units (delta_q in c2)
+      else { A16_M8(mx1, mx0, 1); }
+#undef A16_M8
+    } else {
+      mx0 = sacc[0][0][0], mx1 = sacc[0][1][0];
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
+      for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { mx0 = fmaxf(mx0, sacc[kb][0][e]); mx1 = fmaxf(mx1, sacc[kb][1][e]); }
+        for (int e = 0; e < 4; ++e) { mx0 = fmaxf(mx0, sacc[kb][0][e]); mx1 = fmaxf(mx1, sacc[kb][1][e]); }
+    }
     const bool first = (j == jt0);
     if (QK8) {
       // scores are dot * delta_k here; c2 = delta_q * scale * log2(e) is per lane and query block.  Running maximum in score
@@ -894,14 +978,23 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
           m_run[nq] = m_new;
           l_run[nq] *= alpha;
 #pragma unroll
+          for (int r = 0; r < 4; ++r) lacc[nq][r] *= alpha;
+#pragma unroll
           for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[i][nq][r] *= alpha;
         }
       }
-    } else if (first || __any(fmaxf(mx0, mx1) > 6.0f)) {
+    } else if (first || (!WANQ_ABL_NOMAX && __any((WANQ_ATTN_MAX3 ? mx1 : fmaxf(mx0, mx1)) > 6.0f))) {
       asm volatile("" ::: "memory");  // keep this a branch
       float mx[2] = {mx0, mx1};
+      if (WANQ_ATTN_MAX3) {  // mx1 covers both query blocks: the block's own maximum, here only
+        mx[1] = sacc[0][1][0];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) mx[1] = fmaxf(mx[1], sacc[kb][1][e]);
+      }
 #pragma unroll
       for (int nq = 0; nq < 2; ++nq) {
         float m = mx[nq];
@@ -911,6 +1004,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
         if (!first) {
           const float alpha = __builtin_amdgcn_exp2f(-delta);
           l_run[nq] *= alpha;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lacc[nq][r] *= alpha;
 #pragma unroll
           for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -931,9 +1026,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
     bf16x8 pf[2][2];
 #define A16_EXP(kb, nq, e)                                                     \
   {                                                                            \
-    const float x_ = __builtin_amdgcn_exp2f(QK8 ? fmaf(sacc[kb][nq][e], c2[nq], -mc[nq]) : sacc[kb][nq][e]); \
-    if (nq == 0) { ls0 += x_; asm volatile("" : "+v"(ls0)); }                  \
-    else { ls1 += x_; asm volatile("" : "+v"(ls1)); }                          \
+    const float x_ = WANQ_ABL_NOEXP ? sacc[kb][nq][e] * 0.001f : __builtin_amdgcn_exp2f(QK8 ? fmaf(sacc[kb][nq][e], c2[nq], -mc[nq]) : sacc[kb][nq][e]); \
+    if (!LSUM) {                                                               \
+      if (nq == 0) { ls0 += x_; asm volatile("" : "+v"(ls0)); }                \
+      else { ls1 += x_; asm volatile("" : "+v"(ls1)); }                        \
+    }                                                                          \
     pf[(kb) >> 1][nq][4 * ((kb) & 1) + (e)] = (__bf16)x_;                      \
   }
 #define A16_EXP4(kb, nq) A16_EXP(kb, nq, 0) A16_EXP(kb, nq, 1) A16_EXP(kb, nq, 2) A16_EXP(kb, nq, 3)
@@ -949,6 +1046,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
   asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(P##0), "+v"(P##1), "+v"(P##2), "+v"(P##3), "+v"(P##4), "+v"(P##5), "+v"(P##6), "+v"(P##7))
 #define A16_PV(P, a, b, ks, db, nq) o[db][nq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at_join(P##a, P##b), pf[ks][nq], o[db][nq], 0, 0, 0)
 #define A16_F() __builtin_amdgcn_sched_barrier(0)
+#define A16_LS(ks, nq) if (LSUM) lacc[nq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[ks][nq], lacc[nq], 0, 0, 0)
     A16_TR8(ta, 0, va0, va1, va2, va3);
     A16_TR8(tb, 0, va4, va5, va6, va7);
     A16_EXP4(0, 0) A16_EXP4(1, 0) A16_EXP4(0, 1) A16_EXP4(1, 1)
@@ -959,6 +1057,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
     A16_PV(ta, 2, 3, 0, 1, 0); A16_F(); A16_EXP(2, 0, 2) A16_F(); A16_PV(ta, 2, 3, 0, 1, 1); A16_F(); A16_EXP(2, 0, 3) A16_F();
     A16_PV(ta, 4, 5, 0, 2, 0); A16_F(); A16_EXP(3, 0, 0) A16_F(); A16_PV(ta, 4, 5, 0, 2, 1); A16_F(); A16_EXP(3, 0, 1) A16_F();
     A16_PV(ta, 6, 7, 0, 3, 0); A16_F(); A16_EXP(3, 0, 2) A16_F(); A16_PV(ta, 6, 7, 0, 3, 1); A16_F(); A16_EXP(3, 0, 3) A16_F();
+    A16_LS(0, 0); A16_LS(0, 1);
     A16_TR8(ta, 1, va0, va1, va2, va3);
     A16_WAIT8(tb, 8);
     A16_PV(tb, 0, 1, 0, 4, 0); A16_F(); A16_EXP(2, 1, 0) A16_F(); A16_PV(tb, 0, 1, 0, 4, 1); A16_F(); A16_EXP(2, 1, 1) A16_F();
@@ -969,11 +1068,15 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
     A16_WAIT8(ta, 8);
     A16_PV(ta, 0, 1, 1, 0, 0); A16_PV(ta, 0, 1, 1, 0, 1); A16_PV(ta, 2, 3, 1, 1, 0); A16_PV(ta, 2, 3, 1, 1, 1);
     A16_PV(ta, 4, 5, 1, 2, 0); A16_PV(ta, 4, 5, 1, 2, 1); A16_PV(ta, 6, 7, 1, 3, 0); A16_PV(ta, 6, 7, 1, 3, 1);
+    A16_LS(1, 0); A16_LS(1, 1);
     A16_WAIT8(tb, 0);
     A16_PV(tb, 0, 1, 1, 4, 0); A16_PV(tb, 0, 1, 1, 4, 1); A16_PV(tb, 2, 3, 1, 5, 0); A16_PV(tb, 2, 3, 1, 5, 1);
     A16_PV(tb, 4, 5, 1, 6, 0); A16_PV(tb, 4, 5, 1, 6, 1); A16_PV(tb, 6, 7, 1, 7, 0); A16_PV(tb, 6, 7, 1, 7, 1);
-    l_run[0] += ls0;
-    l_run[1] += ls1;
+    if (!LSUM) {
+      l_run[0] += ls0;
+      l_run[1] += ls1;
+    }
+#undef A16_LS
 #undef A16_EXP
 #undef A16_EXP4
 #undef A16_TR
@@ -996,9 +1099,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
   // ---- epilogue: O[q, d] = O^T[d, q] / l ; lane holds d = 16 db + 4 g4 + e of query 16 nq + n16
 #pragma unroll
   for (int nq = 0; nq < 2; ++nq) {
-    float l = l_run[nq];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    float l;
+    if (LSUM) {
+      l = lacc[nq][0];  // row (any) x column n16 of the ones . P^T product: the whole row sum of query 16 nq + n16
+    } else {
+      l = l_run[nq];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    }
     if (SPLIT) {  // unnormalised partials; attn_combine_kernel merges the splits
       const int qs = q0 + 16 * nq + n16;
       if (qs < p.Lq) {
