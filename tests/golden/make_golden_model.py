@@ -175,12 +175,19 @@ def main():
             mod.a_quantizer.module_name = name
     apply_func_to_submodules(model, class_type=BaseQuantizer, function=set_init_done_)
     stages.clear()
-    hq = [model.blocks[0].register_forward_hook(lambda mod, a, k, o: stages.__setitem__("qb0", o.clone()), with_kwargs=True)]
+    # every quantised block's input and output (teacher-forced per-block parity: a block fed the reference's own block input;
+    # `e` and `context` are those of the FP run -- time / text embeddings stay FP -- and block 0's input is `block0_in`)
+    hq = [model.blocks[0].register_forward_hook(lambda mod, a, k, o: stages.__setitem__("qb0", o.clone()), with_kwargs=True),
+          model.blocks[1].register_forward_pre_hook(lambda mod, a, k: stages.__setitem__("qb1_in", a[0].clone()), with_kwargs=True),
+          model.blocks[1].register_forward_hook(lambda mod, a, k, o: stages.__setitem__("qb1", o.clone()), with_kwargs=True)]
     builtins.print = lambda *a, **k: None
     out_q = model([x], t, [ctx], seq_len)[0]
     builtins.print = real_print
-    hq[0].remove()
+    for h in hq:
+        h.remove()
     arrs["quant_out"], arrs["quant_block0_out"] = out_q, stages["qb0"]
+    assert torch.equal(stages["qb1_in"], stages["qb0"])
+    arrs["quant_block1_out"] = stages["qb1"]
     # every quantized Linear of block 0 on its own: seeded inputs (regenerable from the layer's name) -> its simulation-mode output
     for n_, mod in model.blocks[0].named_modules():
         if hasattr(mod, "w_quantizer"):

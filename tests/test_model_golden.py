@@ -252,3 +252,84 @@ def test_kernel_mode_model_vs_reference_simulation_mode(gm):
     # (every re-quantisation flips a code now and then; bf16 attention on top): bar = the reference's own quantized-vs-FP gap
     gap = rel(ref, ref_fp)
     assert rel(sim, ref) < 1.5 * gap and rel(hw, ref) < 1.5 * gap and rel(hw, ref_fp) < 2.5 * gap
+
+
+def _tiny_quant_model():
+    """This repository's QuantWanModel with the fixture's parameters, masks and rotations (the model of
+    test_kernel_mode_model_vs_reference_simulation_mode), in simulation mode."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "wan2.1-quantization_amd"))
+    from qdiff import config as qcfg
+    from wan.modules.model import WanModel
+    from wan.quant_wanx import QuantWanModel
+
+    torch.manual_seed(0)
+    with torch.device("cuda"):
+        fp = WanModel(model_type="t2v", patch_size=(1, 2, 2), text_len=32, in_dim=16, dim=256, ffn_dim=512, freq_dim=64, text_dim=64,
+                      out_dim=16, num_heads=2, num_layers=2, eps=1e-6).eval()
+    seeded_parameters_(fp)
+    cfg = qcfg.create({"remain_fp_regex": r"text_embedding|time_embedding|time_projection|head\.head",
+                       "weight": {"n_bits": 8, "sym": False}, "act": {"n_bits": 8, "sym": True},
+                       "viditq": {"alpha": 0.5665, "layer_name_regex": r"self_attn\.(q|k|v)$"}})
+    model = QuantWanModel.from_float(fp, cfg)
+    model.quant_layer_refactor()
+    for name, mod in model.named_modules():
+        if type(mod).__name__ == "ViDiTQuantizedLinear":
+            act_mask, signs = seeded_vidit(name, mod.in_features)
+            mod.get_channel_mask(act_mask.cuda())
+            mod.rotation_signs = signs
+            mod.update_quantized_weight_rotated_and_scaled()
+    model.set_init_done()
+    return model.eval()
+
+
+@pytest.mark.gpu
+def test_kernel_mode_blocks_teacher_forced_vs_reference_simulation_mode(gm):
+    """block-level parity that can tell a faithful implementation from a merely similar quantiser.  Every
+    kernel-mode block is fed the REFERENCE'S OWN block input of its simulation-mode run (block 0: `block0_in`; block 1: the
+    reference's `quant_block0_out`), with its `e` and `context`, and compared with the reference's output of that block
+    (W/wan/quant_wanx_cuda.py:170-310 dataflow, Q/viditq/viditq_quant_layer.py:52-73 layers) -- no error is carried from
+    block to block.  Three configurations, each with its own stated bar:
+      (a) fp32 activations, attention core = the fp32 softmax definition (exactly what the fixture's generator gave the
+          reference in place of the external flash_attn): what is left is the quantised-Linear path itself -- fp32 LayerNorm /
+          transform / quantiser reduction order against the reference's, where a last-bit difference flips an int8 code at a .5
+          boundary now and then.  Bar 1e-3 (a wrong zero-point term, scale or rotation sign moves a block by > 1e-2).
+      (b) fp32 activations, the HIP attention kernel (bf16 operands, bf16 P): + the attention core's bf16 rounding.  Bar 2e-3.
+      (c) the shipped configuration (bf16 activations between the kernels).  Bar 5e-3; the fake-quant-vs-FP gap of a block is 6-9e-3."""
+    from wan import ops
+    from wan.quant_wanx_hip import _FpSrc
+
+    model = _tiny_quant_model()
+    e0 = torch.from_numpy(gm["block0_e"]).cuda().float()
+    ctx = torch.from_numpy(gm["block0_context"])[0].cuda().float().contiguous()
+    rope = model._rope((3, 4, 3), torch.device("cuda"))
+    blocks_io = [(gm["block0_in"][0], gm["quant_block0_out"][0], gm["block0_out"][0]),
+                 (gm["quant_block0_out"][0], gm["quant_block1_out"][0], None)]
+
+    def rel(a, b):
+        return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+    def fp32_attention(q, k, v, num_heads, k_len=None, out=None, splits=None):
+        Lq, C = q.shape
+        d = C // num_heads
+        kl = k.shape[0] if k_len is None else min(int(k_len), k.shape[0])
+        s = torch.einsum("qhd,khd->hqk", q.float().view(Lq, num_heads, d), k.float().view(-1, num_heads, d)[:kl]) / d ** 0.5
+        return torch.einsum("hqk,khd->qhd", torch.softmax(s, dim=-1), v.float().view(-1, num_heads, d)[:kl]).reshape(Lq, C).to(torch.bfloat16 if q.dtype == torch.bfloat16 else torch.float32)
+
+    real_attention = ops.attention
+    results = {}
+    try:
+        for tag, act_dtype, attn, bar in (("a", torch.float32, fp32_attention, 1e-3), ("b", torch.float32, real_attention, 2e-3),
+                                          ("c", torch.bfloat16, real_attention, 5e-3)):
+            ops.attention = attn
+            model.hardware_forward_refactor(act_dtype=act_dtype)
+            for i, (xin, ref, ref_fp) in enumerate(blocks_io):
+                x = torch.from_numpy(xin).cuda().float().contiguous().clone()
+                out = model.hip_blocks[i](x, e0, rope, 36, _FpSrc(ctx, act_dtype)).float().cpu().numpy()
+                err = rel(out[:36], ref[:36])  # real tokens (the 4 padding rows never reach the model output)
+                results[(tag, i)] = err
+                assert err < bar, (tag, i, err, bar)
+    finally:
+        ops.attention = real_attention
+    gap = rel(blocks_io[0][2][:36], blocks_io[0][1][:36])
+    print("teacher-forced kernel-mode blocks vs the reference's simulation mode: " +
+          ", ".join(f"({t}) block {i} {e:.2e}" for (t, i), e in sorted(results.items())) + f"; fake-quant vs FP of block 0: {gap:.2e}")

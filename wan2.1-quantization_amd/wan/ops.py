@@ -221,7 +221,11 @@ def attention(q, k, v, num_heads, k_len=None, out=None, splits=None):
     """softmax(q k^T / sqrt(d)) v for one sample on the HIP flash-attention kernel (csrc/attention.hip).
     q [Lq, C], k/v [Lk, C] bf16, token-major (row stride may exceed C: column slices of a packed buffer are
     fine) -> [Lq, C].  k_len masks key padding (flash_attention(..., k_lens), wan/modules/attention.py:78-80).
-    splits: None = attention_splits() decides; 1 = one workgroup per (query block, head); n = split-KV."""
+    splits: None = attention_splits() decides; 1 = one workgroup per (query block, head); n = split-KV.
+    fp32 operands (the kernel-mode block built with act_dtype=float32, a parity-test configuration) are rounded to bf16 here:
+    bf16 operands and a bf16 P are the kernel's contract, as they are flash_attn's in the reference."""
+    if q.dtype == torch.float32 and k.dtype == torch.float32 and v.dtype == torch.float32:
+        q, k, v = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
     Lq, C = q.shape
     d = C // num_heads
     for n, t in (("q", q), ("k", k), ("v", v)):
