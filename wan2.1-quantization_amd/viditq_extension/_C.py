@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libwanq_hip.so")
+# WANQ_LIB: another build of the same library (lib/variants/*.so from tools/probes/attn_variants_build.sh), for whole-step A/B runs
+LIB_PATH = os.environ.get("WANQ_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libwanq_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
