@@ -110,15 +110,13 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const PrepParams p) {
       float m = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[i][j]));
-#define PREP_XMAX(o) m = fmaxf(m, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(m), ((o) << 10) | 0x1f)))
-      PREP_XMAX(1); PREP_XMAX(2); PREP_XMAX(4); PREP_XMAX(8);  // lane ^ o inside the head's 16 lanes
-#undef PREP_XMAX
+      // lane ^ o inside the head's 16 lanes (DPP: wanq_common.h)
+      m = fmaxf(m, lane_xor_dpp<1>(m)); m = fmaxf(m, lane_xor_dpp<2>(m)); m = fmaxf(m, lane_xor_dpp<4>(m)); m = fmaxf(m, lane_xor_dpp<8>(m));
       float scale = m / 127.0f;
       if (scale < 1e-6f) scale = 1e-6f;  // qdiff eps rule (base_quantizer.py:122-127)
-      int qi[8];
-      quant8_div_rne(v[i], scale, 1.0f / scale, qi);
-      *reinterpret_cast<uint2*>(p.q8 + rbase + c0) =
-          make_uint2(pack4_i8_fast(qi[0], qi[1], qi[2], qi[3]), pack4_i8_fast(qi[4], qi[5], qi[6], qi[7]));
+      uint32_t pk[2];
+      quantN_pack_rne<8>(v[i], scale, 1.0f / scale, pk);
+      *reinterpret_cast<uint2*>(p.q8 + rbase + c0) = make_uint2(pk[0], pk[1]);
       if ((lane & 15) == 0) {
         const int64_t so = (int64_t)(c0 >> 7) * p.scale_stride + row;
         p.qscale[so] = scale;

@@ -96,38 +96,45 @@ struct IoN<F16, 4> {
   }
 };
 
-// value of lane ^ MASK (MASK < 32: ds_swizzle bit mode, and 0x1f / or 0 / xor MASK; MASK == 32: ds_bpermute)
+// value of lane ^ MASK: DPP for 1, 2, 4, 8 (wanq_common.h); 16: ds_swizzle bit mode; 32: ds_bpermute.  The butterfly stages and
+// the reductions below do not use the 16 / 32 forms: they take both members of a pair from one v_permlane16/32_swap.
 template <int MASK>
 __device__ __forceinline__ float lane_xor(float v) {
-  if constexpr (MASK < 32) return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (MASK << 10) | 0x1f));
-  else return __shfl_xor(v, 32, 64);
-}
-template <int MASK>
-__device__ __forceinline__ int lane_xor_i(int v) {
-  if constexpr (MASK < 32) return __builtin_amdgcn_ds_swizzle(v, (MASK << 10) | 0x1f);
+  if constexpr (MASK < 16) return lane_xor_dpp<MASK>(v);
+  else if constexpr (MASK < 32) return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (MASK << 10) | 0x1f));
   else return __shfl_xor(v, 32, 64);
 }
 
-// reductions over the LPR = 16, 32 or 64 lanes that own a row
-template <int LPR>
-__device__ __forceinline__ float group_sum(float v) {
-  v += lane_xor<1>(v); v += lane_xor<2>(v); v += lane_xor<4>(v); v += lane_xor<8>(v);
-  if constexpr (LPR >= 32) v += lane_xor<16>(v);
-  if constexpr (LPR >= 64) v += lane_xor<32>(v);
+// reductions over the LPR = 16, 32 or 64 lanes that own a row (order 1, 2, 4, 8, 16, 32: the operand pairs of the lane_xor
+// butterflies this replaces)
+template <int LPR, typename OP>
+__device__ __forceinline__ float group_reduce(float v) {
+  v = OP::f(v, lane_xor_dpp<1>(v)); v = OP::f(v, lane_xor_dpp<2>(v)); v = OP::f(v, lane_xor_dpp<4>(v)); v = OP::f(v, lane_xor_dpp<8>(v));
+  if constexpr (LPR >= 32) {
+    const uint2 r = pair16(__float_as_int(v));
+    v = OP::f(__uint_as_float(r.x), __uint_as_float(r.y));
+  }
+  if constexpr (LPR >= 64) {
+    const uint2 r = pair32(__float_as_int(v));
+    v = OP::f(__uint_as_float(r.x), __uint_as_float(r.y));
+  }
   return v;
 }
 template <int LPR>
-__device__ __forceinline__ float group_max(float v) {
-  v = fmaxf(v, lane_xor<1>(v)); v = fmaxf(v, lane_xor<2>(v)); v = fmaxf(v, lane_xor<4>(v)); v = fmaxf(v, lane_xor<8>(v));
-  if constexpr (LPR >= 32) v = fmaxf(v, lane_xor<16>(v));
-  if constexpr (LPR >= 64) v = fmaxf(v, lane_xor<32>(v));
-  return v;
-}
+__device__ __forceinline__ float group_sum(float v) { return group_reduce<LPR, OpSum>(v); }
+template <int LPR>
+__device__ __forceinline__ float group_max(float v) { return group_reduce<LPR, OpMax>(v); }
 template <int LPR>
 __device__ __forceinline__ int group_isum(int v) {
-  v += lane_xor_i<1>(v); v += lane_xor_i<2>(v); v += lane_xor_i<4>(v); v += lane_xor_i<8>(v);
-  if constexpr (LPR >= 32) v += lane_xor_i<16>(v);
-  if constexpr (LPR >= 64) v += lane_xor_i<32>(v);
+  v += lane_xor_dpp<1>(v); v += lane_xor_dpp<2>(v); v += lane_xor_dpp<4>(v); v += lane_xor_dpp<8>(v);
+  if constexpr (LPR >= 32) {
+    const uint2 r = pair16(v);
+    v = (int)r.x + (int)r.y;
+  }
+  if constexpr (LPR >= 64) {
+    const uint2 r = pair32(v);
+    v = (int)r.x + (int)r.y;
+  }
   return v;
 }
 
@@ -157,13 +164,24 @@ constexpr bool is_pow2_c(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
 // one lane-exchange butterfly stage on every element: v <- other + sgn * v, sgn = -1 on the lane whose bit is set
 // (bit clear: v + other; bit set: other - v): one rounding, identical to the add / subtract form
+// MASK 1 .. 8: the partner arrives as a DPP operand of the add (sgn * v is exact, so mul + add rounds like the fma did);
+// MASK 16 / 32: one v_permlane16/32_swap hands both lanes of a pair the lower member (.x) and the upper member (.y):
+// lower lane v + other = x + y, upper lane other - v = x - y, i.e. fma(sgn, y, x).  Same operands, same single rounding as the
+// ds_swizzle form: bit-identical.
 template <int MASK, int KIN, int EPL>
 __device__ __forceinline__ void lane_stage(float (&v)[KIN][EPL], int lane) {
   const float sgn = (lane & MASK) ? -1.f : 1.f;
 #pragma unroll
   for (int r = 0; r < KIN; ++r) {
 #pragma unroll
-    for (int j = 0; j < EPL; ++j) v[r][j] = fmaf(sgn, v[r][j], lane_xor<MASK>(v[r][j]));
+    for (int j = 0; j < EPL; ++j) {
+      if constexpr (MASK < 16) {
+        v[r][j] = sgn * v[r][j] + lane_xor_dpp<MASK>(v[r][j]);
+      } else {
+        const uint2 pr = MASK == 16 ? pair16(__float_as_int(v[r][j])) : pair32(__float_as_int(v[r][j]));
+        v[r][j] = fmaf(sgn, __uint_as_float(pr.y), __uint_as_float(pr.x));
+      }
+    }
     ROT_FENCE(r);
   }
 }
@@ -305,27 +323,8 @@ __device__ __forceinline__ void rot_normalise(const RotParams& p, int col0, int6
   }
 }
 
-// q = clamp(rne(x / s)) with IEEE division semantics for EPL elements (see quant8_div_rne in wanq_common.h)
-template <int EPL>
-__device__ __forceinline__ void quantN_div_rne(const float (&x)[EPL], float s, float inv, int (&q)[EPL]) {
-  float r[EPL];
-  bool near = false;
-#pragma unroll
-  for (int j = 0; j < EPL; ++j) {
-    const float t = x[j] * inv;
-    r[j] = rintf(t);
-    near |= fabsf(t - r[j]) >= fmaf(-4e-7f, fabsf(t), 0.5f);
-  }
-  if (near) {
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) r[j] = rintf(x[j] / s);
-  }
-#pragma unroll
-  for (int j = 0; j < EPL; ++j) q[j] = (int)__builtin_amdgcn_fmed3f(r[j], -128.f, 127.f);
-}
-
 // Waves per SIMD the register allocator must leave room for: the row (EPL * KIN floats) plus ~100 working registers.
-constexpr int rot_waves_per_simd(int row_regs) { return row_regs <= 8 ? 4 : row_regs <= 64 ? 3 : 2; }
+constexpr int rot_waves_per_simd(int row_regs) { return row_regs <= 8 ? 4 : row_regs <= 48 ? 3 : 2; }  // (64 floats per lane + the DPP forms' temporaries spill at 168 registers)
 
 // KIN blocks per lane, Q lane groups per row (K' = Q * KIN), EPL elements of a block per lane.  A MULTI launch produces the
 // normalised row again from x for every set after the first (the wave has just read it: L1 / L2 hits) instead of keeping
@@ -429,17 +428,13 @@ __global__ __launch_bounds__(256, rot_waves_per_simd(KIN* EPL * ((MULTI && KIN *
     int isum = 0;
 #pragma unroll
     for (int r = 0; r < KIN; ++r) {
-      int qi[EPL];
-#ifdef WANQ_ROT_ABLATE_QUANT
-      for (int j = 0; j < EPL; ++j) qi[j] = (int)(v[r][j] * inv);
-#else
-      quantN_div_rne<EPL>(v[r], scale, inv, qi);
-#endif
+      uint32_t pk[EPL / 4];
+      quantN_pack_rne<EPL>(v[r], scale, inv, pk);  // (dynamic scale: |v / scale| <= 127.5)
       int8_t* dst = q8 + rbase + col0 + 128 * r;
-      const uint32_t lo = pack4_i8_fast(qi[0], qi[1], qi[2], qi[3]);
+      const uint32_t lo = pk[0];
       isum = __builtin_amdgcn_sdot4((int)lo, 0x01010101, isum, false);  // sum of the four signed bytes
       if constexpr (EPL == 8) {
-        const uint32_t hi = pack4_i8_fast(qi[4], qi[5], qi[6], qi[7]);
+        const uint32_t hi = pk[EPL / 4 - 1];
         isum = __builtin_amdgcn_sdot4((int)hi, 0x01010101, isum, false);
         if (live) *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
       } else {

@@ -305,9 +305,9 @@ __global__ __launch_bounds__(256, 2) void rotate140_kernel(const Rot140Params p)
       for (int ps = 0; ps < R140_PASSES; ++ps) {
         const int b = (tid >> 3) + 32 * ps;
         if (b < R140_K) {
-          int qi[8];
-          quant8_div_rne(v[ps], scale, inv, qi);
-          const uint32_t lo = pack4_i8_fast(qi[0], qi[1], qi[2], qi[3]), hi = pack4_i8_fast(qi[4], qi[5], qi[6], qi[7]);
+          uint32_t pk[2];
+          quantN_pack_rne<8>(v[ps], scale, inv, pk);
+          const uint32_t lo = pk[0], hi = pk[1];
           isum = __builtin_amdgcn_sdot4((int)lo, 0x01010101, isum, false);
           isum = __builtin_amdgcn_sdot4((int)hi, 0x01010101, isum, false);
           *reinterpret_cast<uint2*>(p.q + rbase + b * 64 + c8) = make_uint2(lo, hi);

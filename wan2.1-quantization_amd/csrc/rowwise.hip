@@ -221,9 +221,16 @@ __global__ __launch_bounds__(256) void rowwise_kernel(const RowParams p) {
   int isum = 0;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    int qi[8];
-    quant8_div_rne(v[i], scale, inv, qi);
-    const uint32_t lo = pack4_i8_fast(qi[0], qi[1], qi[2], qi[3]), hi = pack4_i8_fast(qi[4], qi[5], qi[6], qi[7]);
+    uint32_t lo, hi;
+    if (p.static_amax) {  // a given scale: values may exceed the code range and are clamped
+      int qi[8];
+      quant8_div_rne(v[i], scale, inv, qi);
+      lo = pack4_i8_fast(qi[0], qi[1], qi[2], qi[3]), hi = pack4_i8_fast(qi[4], qi[5], qi[6], qi[7]);
+    } else {              // the row's own scale: |v / scale| <= 127.5 by construction
+      uint32_t pk[2];
+      quantN_pack_rne<8>(v[i], scale, inv, pk);
+      lo = pk[0], hi = pk[1];
+    }
     isum = __builtin_amdgcn_sdot4((int)lo, 0x01010101, isum, false);  // sum of the four signed bytes
     isum = __builtin_amdgcn_sdot4((int)hi, 0x01010101, isum, false);
     if (ok[i]) *reinterpret_cast<uint2*>(p.q + rbase + (sub * 64 + lane + i * 64 * WPR) * 8) = make_uint2(lo, hi);

@@ -43,25 +43,67 @@ int rotate140_rows(const void* x, int x_dtype, const float* premul, void* out_fp
 inline bool is_fp(int dt) { return dt == WANQ_F16 || dt == WANQ_BF16 || dt == WANQ_F32; }
 inline bool is_vec(int dt) { return dt == WANQ_F16 || dt == WANQ_F32; }
 
-// ---------------------------------------------------------------- device: wave64 reductions
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+// ---------------------------------------------------------------- device: wave64 lane exchanges and reductions
+// Value of lane ^ MASK for MASK in {1, 2, 4, 8}: DPP operand modifiers of the vector ALU (hipcc folds them into the consuming
+// add / max: v_add_f32_dpp ...).  The ds_swizzle / ds_bpermute forms they replace go through the LDS crossbar: 100-300 cycles of
+// latency per step under load, which a dependent reduction chain (six steps) or a butterfly stage pays in full; SQ counters of
+// the transform kernel had 46 % of its wave cycles parked behind them (profiles/r03_h_rowwise_sq.csv).
+//   xor 1, 2: quad_perm;  xor 8: row_ror:8 (a rotation by half a 16-lane row);  xor 4: row_shl:4 for the lanes whose bit 2 is
+//   clear (banks 0, 2) + row_shr:4 for the others (banks 1, 3), two moves into one register.
+template <int MASK>
+__device__ __forceinline__ int lane_xor_dpp(int v) {
+  static_assert(MASK == 1 || MASK == 2 || MASK == 4 || MASK == 8, "DPP lane exchange: masks inside a 16-lane row");
+  if constexpr (MASK == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);        // quad_perm:[1,0,3,2]
+  else if constexpr (MASK == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);   // quad_perm:[2,3,0,1]
+  else if constexpr (MASK == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, true);  // row_ror:8
+  else {
+    const int t = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xf, 0x5, false);                      // row_shl:4, banks 0 and 2
+    return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xf, 0xA, false);                             // row_shr:4, banks 1 and 3
+  }
+}
+template <int MASK>
+__device__ __forceinline__ float lane_xor_dpp(float v) { return __int_as_float(lane_xor_dpp<MASK>(__float_as_int(v))); }
+
+// v_permlane16_swap / v_permlane32_swap of a register with itself: .x = the value of the pair's LOWER member (even 16-lane row /
+// lanes 0-31), .y = of the UPPER member, in both lanes of every (lane, lane ^ 16) / (lane, lane ^ 32) pair
+__device__ __forceinline__ uint2 pair16(int v) {
+  const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+  return make_uint2(r[0], r[1]);
+}
+__device__ __forceinline__ uint2 pair32(int v) {
+  const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+  return make_uint2(r[0], r[1]);
+}
+
+// Wave reductions in the order 32, 16, 8, 4, 2, 1 (the operand pairs, and with them every rounding, are those of the
+// __shfl_xor butterflies these replace: bit-identical results)
+struct OpSum { template <typename T> static __device__ __forceinline__ T f(T a, T b) { return a + b; } };
+struct OpMax { static __device__ __forceinline__ float f(float a, float b) { return fmaxf(a, b); } };
+struct OpMin { static __device__ __forceinline__ float f(float a, float b) { return fminf(a, b); } };
+template <typename OP>
+__device__ __forceinline__ float wave_reduce(float v) {
+  uint2 r = pair32(__float_as_int(v));
+  v = OP::f(__uint_as_float(r.x), __uint_as_float(r.y));
+  r = pair16(__float_as_int(v));
+  v = OP::f(__uint_as_float(r.x), __uint_as_float(r.y));
+  v = OP::f(v, lane_xor_dpp<8>(v));
+  v = OP::f(v, lane_xor_dpp<4>(v));
+  v = OP::f(v, lane_xor_dpp<2>(v));
+  v = OP::f(v, lane_xor_dpp<1>(v));
   return v;
 }
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ __forceinline__ float wave_max(float v) { return wave_reduce<OpMax>(v); }
+__device__ __forceinline__ float wave_min(float v) { return wave_reduce<OpMin>(v); }
+__device__ __forceinline__ float wave_sum(float v) { return wave_reduce<OpSum>(v); }
 __device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  uint2 r = pair32(v);
+  v = (int)r.x + (int)r.y;
+  r = pair16(v);
+  v = (int)r.x + (int)r.y;
+  v += lane_xor_dpp<8>(v);
+  v += lane_xor_dpp<4>(v);
+  v += lane_xor_dpp<2>(v);
+  v += lane_xor_dpp<1>(v);
   return v;
 }
 
@@ -182,6 +224,39 @@ __device__ __forceinline__ void quant8_div_rne(const float (&x)[8], float s, flo
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) q[j] = (int)__builtin_amdgcn_fmed3f(r[j], -128.f, 127.f);
+}
+
+// The same quantiser for values KNOWN to satisfy |x / s| <= 127.5 (a dynamic per-row scale s = amax / 127, or its eps floor),
+// producing the packed bytes directly, in 4 vector instructions per element + 3 per four for the pack (the form above: 7 + 3):
+//   u = fma(x, inv, M), M = 1.5 * 2^23: the EXACT product x * inv rounded once to the integer grid of [2^23, 2^24) -- the low byte
+//       of u's bit pattern is the two's-complement code (rounding and float -> int in one instruction, no clamp needed);
+//   r = u - M (exact), d = fma(x, inv, -r): the exact residual, |d| <= 0.5;
+//   near: |d| >= 0.5 - 5.1e-5.  RN(x * inv exact) can differ from rint(fl(x / s)) only when x / s lies within
+//       127 * 2^-24 (inv's rounding) + 2^-18 (the quotient's) = 1.2e-5 of a .5 boundary: the threshold keeps a 4x margin, and
+//       the flagged chunk (about 1e-4 of the elements) takes the true division, as above.
+// Bit-identical codes to quant8_div_rne on that domain (tests/test_gpu_rowwise.py: ties, near-ties, eps rows, golden vectors).
+constexpr float WANQ_QMAGIC = 12582912.0f;
+template <int N>
+__device__ __forceinline__ void quantN_pack_rne(const float (&x)[N], float s, float inv, uint32_t (&packed)[N / 4]) {
+  static_assert(N % 4 == 0, "four codes per dword");
+  float u[N];
+  bool near = false;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    u[j] = fmaf(x[j], inv, WANQ_QMAGIC);
+    const float r = u[j] - WANQ_QMAGIC;
+    near |= fabsf(fmaf(x[j], inv, -r)) >= 0.4999488f;
+  }
+  if (near) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) u[j] = rintf(x[j] / s) + WANQ_QMAGIC;
+  }
+#pragma unroll
+  for (int g = 0; g < N / 4; ++g) {
+    const uint32_t b0 = __float_as_uint(u[4 * g]), b1 = __float_as_uint(u[4 * g + 1]), b2 = __float_as_uint(u[4 * g + 2]), b3 = __float_as_uint(u[4 * g + 3]);
+    // bytes (b0.0, b1.0, 0, 0) | (0, 0, b2.0, b3.0)
+    packed[g] = __builtin_amdgcn_perm(b1, b0, 0x0c0c0400u) | __builtin_amdgcn_perm(b3, b2, 0x04000c0cu);
+  }
 }
 
 // 4 ints in [-128,127] -> packed bytes: two saturating i32->i16 packs + one byte permute
