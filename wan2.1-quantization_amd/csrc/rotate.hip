@@ -187,7 +187,7 @@ __device__ __forceinline__ void lane_stage(float (&v)[KIN][EPL], int lane) {
 }
 
 template <int KIN, int Q, int EPL>
-__device__ __forceinline__ void hadamard_regs(float (&v)[KIN][EPL], int lane, float inv_div) {
+__device__ __forceinline__ void hadamard_regs(float (&v)[KIN][EPL], int lane) {  // UNSCALED: the caller owns the 1 / sqrt(n)
   constexpr int LB = 128 / EPL;
   // H_128 inside every block: bits of j ...
 #pragma unroll
@@ -227,16 +227,26 @@ __device__ __forceinline__ void hadamard_regs(float (&v)[KIN][EPL], int lane, fl
         }
   } else {
 #ifndef WANQ_ROT_ABLATE_MIX
+    // Paley-I structure (column 0 all +1, row 0 = (+1, -1, ..., -1), core +1 on the diagonal and chi(a - b) off it): with
+    // S = x_1 + ... + x_{K-1} and P_a = the sum of the x_b, b >= 1, b != a, with chi(a - b) = +1 ((K - 2) / 2 terms),
+    //     y_0 = x_0 - S,     y_a = x_0 + x_a + (2 P_a - (S - x_a)) = (x_0 - S) + 2 (x_a + P_a)
+    // -- 77 additions per column at K = 12 (209 at K = 20) instead of K (K - 1) = 132 (380).
     constexpr MixTable<KIN> tab{};
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
       float t[KIN];
+      float S = v[1][j];
 #pragma unroll
-      for (int a = 0; a < KIN; ++a) {
-        float s = v[0][j];  // column 0 is all +1
+      for (int b = 2; b < KIN; ++b) S += v[b][j];
+      const float base = v[0][j] - S;
+      t[0] = base;
 #pragma unroll
-        for (int b = 1; b < KIN; ++b) s = tab.plus[a][b] ? s + v[b][j] : s - v[b][j];
-        t[a] = s;
+      for (int a = 1; a < KIN; ++a) {
+        float P = v[a][j];
+#pragma unroll
+        for (int b = 1; b < KIN; ++b)
+          if (b != a && tab.plus[a][b]) P += v[b][j];
+        t[a] = fmaf(2.0f, P, base);
       }
 #pragma unroll
       for (int a = 0; a < KIN; ++a) v[a][j] = t[a];
@@ -247,10 +257,6 @@ __device__ __forceinline__ void hadamard_regs(float (&v)[KIN][EPL], int lane, fl
   // S_Q (Sylvester) across the lane groups of the row
   if constexpr (Q >= 2) lane_stage<LB, KIN, EPL>(v, lane);
   if constexpr (Q >= 4) lane_stage<2 * LB, KIN, EPL>(v, lane);
-#pragma unroll
-  for (int r = 0; r < KIN; ++r)
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) v[r][j] *= inv_div;
 }
 
 // One dtype branch per ROW, not per chunk: inside a branch the KIN loads issue back to back (a branch per chunk makes hipcc
@@ -408,9 +414,17 @@ __global__ __launch_bounds__(256, rot_waves_per_simd(KIN* EPL * ((MULTI && KIN *
         ROT_FENCE(r);
       }
     }
-    hadamard_regs<KIN, Q, EPL>(v, lane, p.inv_div);
-
-    if (!MULTI && p.out_fp && live) rot_store_row<KIN, EPL>(p.out_fp, p.out_dtype, rbase + col0, v);
+    hadamard_regs<KIN, Q, EPL>(v, lane);
+    // the 1 / sqrt(n): applied to the values only where they leave as floating point; the quantiser takes it as a factor
+    float cdiv = p.inv_div;
+    if (!MULTI && p.out_fp) {
+#pragma unroll
+      for (int r = 0; r < KIN; ++r)
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) v[r][j] *= cdiv;
+      cdiv = 1.0f;
+      if (live) rot_store_row<KIN, EPL>(p.out_fp, p.out_dtype, rbase + col0, v);
+    }
     int8_t* q8 = p.q[set];
     if (!q8) return;
     void* scale_t = p.scale[set];
@@ -421,15 +435,15 @@ __global__ __launch_bounds__(256, rot_waves_per_simd(KIN* EPL * ((MULTI && KIN *
     for (int r = 0; r < KIN; ++r)
 #pragma unroll
       for (int j = 0; j < EPL; ++j) m = fmaxf(m, fabsf(v[r][j]));
-    const float amax = group_max<LPR>(m);
+    const float amax = group_max<LPR>(m) * cdiv;  // == the maximum of the scaled values (rounding is monotone)
     float scale = amax / 127.0f;
     if (scale < 1e-6f) scale = 1e-6f;  // qdiff eps rule (base_quantizer.py:122-127)
-    const float inv = 1.0f / scale;
+    const float cinv = cdiv * (1.0f / scale);
     int isum = 0;
 #pragma unroll
     for (int r = 0; r < KIN; ++r) {
       uint32_t pk[EPL / 4];
-      quantN_pack_rne<EPL>(v[r], scale, inv, pk);  // (dynamic scale: |v / scale| <= 127.5)
+      quantN_pack_rne_pre<EPL>(v[r], cdiv, scale, cinv, pk);  // (dynamic scale: |v * cdiv / scale| <= 127.5)
       int8_t* dst = q8 + rbase + col0 + 128 * r;
       const uint32_t lo = pk[0];
       isum = __builtin_amdgcn_sdot4((int)lo, 0x01010101, isum, false);  // sum of the four signed bytes

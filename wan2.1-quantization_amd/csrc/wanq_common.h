@@ -259,6 +259,32 @@ __device__ __forceinline__ void quantN_pack_rne(const float (&x)[N], float s, fl
   }
 }
 
+// quantN_pack_rne for x = fl(y * c) WITHOUT forming x: the codes of rne(fl(y * c) / s), c > 0 a per-launch constant (the
+// 1 / sqrt(n) of the Hadamard transform), from u = fma(y, fl(c * inv), M).  The exact y * fl(c * inv) lies within
+// 127 * 3 * 2^-24 + 2^-18 = 2.7e-5 of fl(fl(y * c) / s), inside the same threshold; the flagged chunk evaluates the
+// reference's two operations literally.  (The row maximum commutes with the scaling: fl(max|y| * c) == max fl(|y| * c).)
+template <int N>
+__device__ __forceinline__ void quantN_pack_rne_pre(const float (&y)[N], float c, float s, float cinv, uint32_t (&packed)[N / 4]) {
+  static_assert(N % 4 == 0, "four codes per dword");
+  float u[N];
+  bool near = false;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    u[j] = fmaf(y[j], cinv, WANQ_QMAGIC);
+    const float r = u[j] - WANQ_QMAGIC;
+    near |= fabsf(fmaf(y[j], cinv, -r)) >= 0.4999488f;
+  }
+  if (near) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) u[j] = rintf((y[j] * c) / s) + WANQ_QMAGIC;
+  }
+#pragma unroll
+  for (int g = 0; g < N / 4; ++g) {
+    const uint32_t b0 = __float_as_uint(u[4 * g]), b1 = __float_as_uint(u[4 * g + 1]), b2 = __float_as_uint(u[4 * g + 2]), b3 = __float_as_uint(u[4 * g + 3]);
+    packed[g] = __builtin_amdgcn_perm(b1, b0, 0x0c0c0400u) | __builtin_amdgcn_perm(b3, b2, 0x04000c0cu);
+  }
+}
+
 // 4 ints in [-128,127] -> packed bytes: two saturating i32->i16 packs + one byte permute
 __device__ __forceinline__ uint32_t pack4_i8_fast(int a, int b, int c, int d) {
   typedef short s16x2 __attribute__((ext_vector_type(2)));
