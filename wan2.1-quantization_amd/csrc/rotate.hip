@@ -164,25 +164,75 @@ constexpr bool is_pow2_c(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
 // one lane-exchange butterfly stage on every element: v <- other + sgn * v, sgn = -1 on the lane whose bit is set
 // (bit clear: v + other; bit set: other - v): one rounding, identical to the add / subtract form
-// MASK 1 .. 8: the partner arrives as a DPP operand of the add (sgn * v is exact, so mul + add rounds like the fma did);
-// MASK 16 / 32: one v_permlane16/32_swap hands both lanes of a pair the lower member (.x) and the upper member (.y):
-// lower lane v + other = x + y, upper lane other - v = x - y, i.e. fma(sgn, y, x).  Same operands, same single rounding as the
-// ds_swizzle form: bit-identical.
+// One lane-exchange butterfly stage at two vector instructions per element and no LDS traffic (bit 'MASK' of the lane
+// clear: v + other; set: other - v -- the operands and the single rounding of the ds_swizzle + fma form: bit-identical):
+//   MASK 1, 2  (inside a quad: bank masks cannot tell the two lanes of a pair apart)  t = +-v by v_cndmask, then
+//              v_add_f32_dpp quad_perm.  The four t of a block are made before the four adds: a DPP instruction must not
+//              read a register written by one of the two instructions in front of it (hipcc pads with s_nop 1 otherwise --
+//              899 of them in the first DPP build of the q / k / v kernel, which reused one temporary);
+//   MASK 4, 8  v_add_f32_dpp row_shl:MASK on the banks whose lanes have the bit clear + v_sub_f32_dpp row_shr:MASK on the
+//              others, into one register (inline asm: the masked forms have no builtin; leading s_nop 1 = the hazard above
+//              for inputs written just in front of the statement);
+//   MASK 16, 32  two elements p, q at a time through v_permlane16/32_swap: swap(p, q) leaves (p_lo, q_lo) in one register
+//              and (p_hi, q_hi) in the other (lo / hi = the pair's lower / upper member), their sum and difference are the
+//              outputs (P_lo, Q_lo) and (P_hi, Q_hi), and a second swap sorts them back into P and Q.
 template <int MASK, int KIN, int EPL>
 __device__ __forceinline__ void lane_stage(float (&v)[KIN][EPL], int lane) {
-  const float sgn = (lane & MASK) ? -1.f : 1.f;
+  if constexpr (MASK <= 2) {
+    const bool neg = (lane & MASK) != 0;
 #pragma unroll
-  for (int r = 0; r < KIN; ++r) {
+    for (int r = 0; r < KIN; ++r) {
+      float t[EPL];
 #pragma unroll
-    for (int j = 0; j < EPL; ++j) {
-      if constexpr (MASK < 16) {
-        v[r][j] = sgn * v[r][j] + lane_xor_dpp<MASK>(v[r][j]);
-      } else {
-        const uint2 pr = MASK == 16 ? pair16(__float_as_int(v[r][j])) : pair32(__float_as_int(v[r][j]));
-        v[r][j] = fmaf(sgn, __uint_as_float(pr.y), __uint_as_float(pr.x));
-      }
+      for (int j = 0; j < EPL; ++j) t[j] = neg ? -v[r][j] : v[r][j];
+      if constexpr (EPL == 4) asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+      else asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) v[r][j] = t[j] + lane_xor_dpp<MASK>(v[r][j]);
+      ROT_FENCE(r);
     }
-    ROT_FENCE(r);
+  } else if constexpr (MASK <= 8) {
+#pragma unroll
+    for (int r = 0; r < KIN; ++r) {
+#pragma unroll
+      for (int j = 0; j < EPL; j += 4) {
+        float o0, o1, o2, o3;
+        if constexpr (MASK == 4)
+          asm volatile("s_nop 1\n\t"
+                       "v_add_f32_dpp %0, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\tv_add_f32_dpp %1, %5, %5 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                       "v_add_f32_dpp %2, %6, %6 row_shl:4 row_mask:0xf bank_mask:0x5\n\tv_add_f32_dpp %3, %7, %7 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                       "v_sub_f32_dpp %0, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa\n\tv_sub_f32_dpp %1, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                       "v_sub_f32_dpp %2, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\tv_sub_f32_dpp %3, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa"
+                       : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+                       : "v"(v[r][j]), "v"(v[r][j + 1]), "v"(v[r][j + 2]), "v"(v[r][j + 3]));
+        else
+          asm volatile("s_nop 1\n\t"
+                       "v_add_f32_dpp %0, %4, %4 row_shl:8 row_mask:0xf bank_mask:0x3\n\tv_add_f32_dpp %1, %5, %5 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+                       "v_add_f32_dpp %2, %6, %6 row_shl:8 row_mask:0xf bank_mask:0x3\n\tv_add_f32_dpp %3, %7, %7 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+                       "v_sub_f32_dpp %0, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xc\n\tv_sub_f32_dpp %1, %5, %5 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+                       "v_sub_f32_dpp %2, %6, %6 row_shr:8 row_mask:0xf bank_mask:0xc\n\tv_sub_f32_dpp %3, %7, %7 row_shr:8 row_mask:0xf bank_mask:0xc"
+                       : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+                       : "v"(v[r][j]), "v"(v[r][j + 1]), "v"(v[r][j + 2]), "v"(v[r][j + 3]));
+        v[r][j] = o0; v[r][j + 1] = o1; v[r][j + 2] = o2; v[r][j + 3] = o3;
+      }
+      ROT_FENCE(r);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < KIN; ++r) {
+#pragma unroll
+      for (int j = 0; j < EPL; j += 2) {
+        const unsigned pb = __float_as_uint(v[r][j]), qb = __float_as_uint(v[r][j + 1]);
+        const auto lohi = MASK == 16 ? __builtin_amdgcn_permlane16_swap(pb, qb, false, false) : __builtin_amdgcn_permlane32_swap(pb, qb, false, false);
+        const float lo = __uint_as_float(lohi[0]), hi = __uint_as_float(lohi[1]);  // (p_lo, q_lo), (p_hi, q_hi)
+        const float su = lo + hi, di = lo - hi;                                        // (P_lo, Q_lo), (P_hi, Q_hi)
+        const auto pq = MASK == 16 ? __builtin_amdgcn_permlane16_swap(__float_as_uint(su), __float_as_uint(di), false, false)
+                                   : __builtin_amdgcn_permlane32_swap(__float_as_uint(su), __float_as_uint(di), false, false);
+        v[r][j] = __uint_as_float(pq[0]);
+        v[r][j + 1] = __uint_as_float(pq[1]);
+      }
+      ROT_FENCE(r);
+    }
   }
 }
 
