@@ -211,6 +211,16 @@ int wanq_attention_map_quant_fwd(const void* q, const void* k, const void* v, vo
                                  int heads, int head_dim, int64_t q_stride, int64_t k_stride, int64_t v_stride,
                                  int64_t o_stride, float scale, int n_bits, int sym, void* workspace,
                                  int64_t workspace_bytes, void* stream);
+/* The reference's FULL quantised-attention recipe in one call (models/quant_opensora.py:431-476: the q / k / v quantisers AND the
+ * attention-map quantiser): q and k as the per-(token, head) int8 codes and fp32 scale planes wanq_rmsnorm_rope_q8 writes
+ * (q_scale / k_scale: plane [heads][stride] of delta; the key plane 16-byte aligned, its stride a multiple of 4 covering whole
+ * 64-key tiles), S = K8 . Q8^T on the int8 matrix cores in all three passes; v is the caller's, already fake-quantised
+ * (wanq_fake_quant_cols).  Same workspace, map quantiser and output as wanq_attention_map_quant_fwd. */
+int wanq_attention_map_quant_qk8_fwd(const int8_t* q8, const float* q_scale, int64_t qs_stride, const int8_t* k8,
+                                     const float* k_scale, int64_t ks_stride, const void* v, void* o, int dtype, int64_t Lq,
+                                     int64_t Lk, int heads, int head_dim, int64_t q8_stride, int64_t k8_stride,
+                                     int64_t v_stride, int64_t o_stride, float scale, int n_bits, int sym, void* workspace,
+                                     int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * ViDiT activation transform fused with the per-token quantiser:

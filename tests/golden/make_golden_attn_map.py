@@ -34,6 +34,24 @@ def main():
         aq = m(attn.clone())
         out[f"attn_q_{tag}"] = aq
         out[f"x_{tag}"] = aq @ v  # quant_opensora.py:476
+    # ---- the FULL recipe of quant_opensora.py:431-476: the q / k / v quantisers (8-bit symmetric DynamicQuantizer with the
+    # reshapes of :431-440: q and k per (token, head) over head_dim, v per (head, channel) over all tokens), the map from the
+    # quantised q and k, the map quantiser, then attn @ v with the quantised v
+    from qdiff.base.base_quantizer import DynamicQuantizer
+    qcfg = OmegaConf.create({"n_bits": 8, "sym": True})
+    qq, kq, vq = DynamicQuantizer(qcfg), DynamicQuantizer(qcfg), DynamicQuantizer(qcfg)
+    for z in (qq, kq, vq):
+        z.module_name = "golden"
+    q8 = qq(q.reshape([-1, D])).reshape([BS, H, N, D])
+    k8 = kq(k.reshape([-1, D])).reshape([BS, H, N, D])
+    v8 = vq(v.permute([0, 1, 3, 2]).reshape([-1, N])).reshape([BS, H, D, N]).permute([0, 1, 3, 2])
+    attn8 = ((q8 * D ** -0.5) @ k8.transpose(-2, -1)).to(torch.float32).softmax(dim=-1)
+    out.update({"full_q8": q8, "full_k8": k8, "full_v8": v8, "full_attn": attn8})
+    for tag, bits, sym in (("8a", 8, False), ("8s", 8, True), ("4s", 4, True)):
+        cfg = OmegaConf.create({"attn": {"attn_map": {"group": "row", "n_bits": bits, "sym": sym}, "qk": {"reorder_file_path": None}}})
+        m = QuantizedAttentionMapOpenSORA(cfg)
+        m.attn_map_quantizer.module_name = "golden"
+        out[f"full_x_{tag}"] = m(attn8.clone()) @ v8
     np.savez_compressed(os.path.join(HERE, "a16_attn_map.npz"), **{k_: t.numpy() for k_, t in out.items()})
     print({k_: tuple(t.shape) for k_, t in out.items()})
 

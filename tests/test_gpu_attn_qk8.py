@@ -273,6 +273,112 @@ def test_attention_map_quant_vs_oracle(Lq, Lk, H, klen, bits, sym):
     assert err.item() < (1.2e-2 if bits == 8 else 0.5 * noise.item() + 1e-2), (err.item(), noise.item())  # 4 bits: well inside the recipe's own noise
 
 
+@pytest.mark.parametrize("Lq,Lk,H,klen,bits,sym", [(45, 45, 3, None, 8, False), (300, 300, 2, None, 8, True), (515, 640, 4, 601, 8, False),
+                                                    (100, 512, 2, None, 4, True), (1000, 777, 2, None, 8, False)])
+def test_full_quantised_attention_recipe_vs_oracle(Lq, Lk, H, klen, bits, sym):
+    """attn.qk + attn.v + attn.attn_map in ONE attention, as the reference applies them (W/models/quant_opensora.py:431-476):
+    q / k as per-(token, head) int8 codes (S on the int8 matrix cores in all three passes), v fake-quantised per (head, channel),
+    the map quantised per key column -- against the oracle's composition (pinned by the fixture's full_* keys,
+    tests/test_oracle_golden.py).  The q / k codes are bit-exact by the quantiser tests; the bar is the map quantiser's."""
+    from viditq_extension import fused
+    from wan import ops
+
+    d = 128
+    g = torch.Generator().manual_seed(Lq * 5 + Lk)
+    q = (torch.randn(Lq, H * d, generator=g) * 1.5).to(torch.bfloat16)
+    k = (torch.randn(Lk, H * d, generator=g) * 1.5).to(torch.bfloat16)
+    v = torch.randn(Lk, H * d, generator=g).to(torch.bfloat16)
+    if Lk > 70:
+        k[69] *= 3.0
+    kl = Lk if klen is None else klen
+    qf, kf, vf = q.float().view(Lq, H, d), k.float().view(Lk, H, d), v.float().view(Lk, H, d)
+    vq = torch.cat([wr.v_fake_quant(vf[:kl], 8), vf[kl:]])
+    ref = wr.attention_map_quant(wr.qk_fake_quant(qf, 8), wr.qk_fake_quant(kf, 8), vq, klen, bits, sym).reshape(Lq, H * d)
+    ident = torch.zeros(max(Lq, Lk), d // 2, 2, device=DEV)
+    ident[..., 0] = 1.0  # rotary = identity, RMSNorm weight None: the kernel only quantises
+    q8 = ops.rmsnorm_rope_q8(q.to(DEV), None, ident, d, False)
+    k8 = ops.rmsnorm_rope_q8(k.to(DEV), None, ident, d, True)
+    vd = v.to(DEV).clone()
+    fused.fake_quant_cols_(vd[:kl], 8)
+    out = ops.attention_map_quant(q8, k8, vd, H, bits, sym, klen).float().cpu()
+    levels = (2 ** (bits - 1) - 1) if sym else (2 ** bits - 1)
+    step = v.float().abs().max().item() / levels
+    err = ((out - ref).norm() / ref.norm()).item()
+    fp = wr.attention(qf, kf, vf, klen).reshape(Lq, H * d)
+    noise = ((ref - fp).norm() / fp.norm()).item()
+    assert torch.isfinite(out).all() and (out - ref).abs().max().item() < 3e-2 + 1.5 * step, (out - ref).abs().max().item()
+    assert err < (1.5e-2 if bits == 8 else 0.5 * noise + 1e-2), (err, noise)
+
+
+def test_full_quantised_attention_recipe_matches_reference_golden():
+    """The same entry point on the fixture's inputs, against the reference's own output of its whole recipe (full_x_*)."""
+    import os
+
+    from viditq_extension import fused
+    from wan import ops
+
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "a16_attn_map.npz")))
+    q, k, v = (torch.from_numpy(g[n])[0].permute(1, 0, 2).reshape(45, 3 * 128).to(torch.bfloat16) for n in ("q", "k", "v"))
+    ident = torch.zeros(45, 64, 2, device=DEV)
+    ident[..., 0] = 1.0
+    q8 = ops.rmsnorm_rope_q8(q.to(DEV), None, ident, 128, False)
+    k8 = ops.rmsnorm_rope_q8(k.to(DEV), None, ident, 128, True)
+    vd = v.to(DEV).clone()
+    fused.fake_quant_cols_(vd, 8)
+    for tag, bits, sym in (("8a", 8, False), ("8s", 8, True), ("4s", 4, True)):
+        out = ops.attention_map_quant(q8, k8, vd, 3, bits, sym).float().cpu().view(45, 3, 128)
+        ref = torch.from_numpy(g[f"full_x_{tag}"])[0].permute(1, 0, 2)
+        # the fixture's q / k / v are fp32; rounding them to bf16 in front of the quantisers moves codes by at most one step
+        assert ((out - ref).norm() / ref.norm()).item() < (6e-2 if bits == 4 else 3e-2)
+
+
+def test_kernel_mode_block_with_the_full_quantised_attention_recipe_vs_oracle():
+    """A kernel-mode block with attn.qk + attn.v + attn.attn_map (and the same for cross-attention) against the simulation oracle
+    with the same three quantisers (BlockRef(qk_bits, v_bits, attn_map)); the config surface accepts the combination."""
+    from test_gpu_block import make_block, rel_err
+    from wan import ops
+    from wan.quant_wanx_hip import WanAttentionBlockWithHipKernel, _FpSrc
+
+    dim, ffn, heads, grid, lc = 512, 1024, 4, (2, 6, 8), 64
+    blk = make_block(dim, ffn, heads, 0)
+    sd = {k_: v_.detach().clone() for k_, v_ in blk.state_dict().items()}
+    n_tok = grid[0] * grid[1] * grid[2]
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n_tok, dim, generator=g)
+    e0 = torch.randn(1, 6, dim, generator=g) * 0.3
+    ctx = torch.randn(lc, dim, generator=g)
+    freqs = wr.rope_freqs(dim // heads)
+    kw = dict(qk_bits=8, cross_qk_bits=8, v_bits=8, cross_v_bits=8, attn_map=(8, False), cross_attn_map=(8, True))
+    ref = wr.block_from_state(sd, heads, quant=True, **kw)(x, e0, grid, n_tok, ctx, freqs)
+    ref_plain = wr.block_from_state(sd, heads, quant=True)(x, e0, grid, n_tok, ctx, freqs)
+    hb = WanAttentionBlockWithHipKernel.from_float(blk.to(DEV), attn_qk8=True, cross_attn_qk8=True, attn_v_bits=8, cross_attn_v_bits=8,
+                                                   attn_map=(8, False), cross_attn_map=(8, True))
+    out = hb(x.to(DEV).clone(), e0.to(DEV), ops.rope_table(freqs, grid, DEV), n_tok, _FpSrc(ctx.to(DEV), torch.bfloat16)).float().cpu()
+    err = rel_err(out, ref)
+    print(f"block with the full quantised-attention recipe: rel err vs recipe oracle {err:.2e}; recipe vs plain-attention oracle {rel_err(ref, ref_plain):.2e}")
+    assert err < 1.5e-2
+
+    from qdiff import config as qcfg
+    from wan.modules.model import WanModel
+    from wan.quant_wanx import QuantWanModel
+
+    base = {"model": {"model_id": "wan2.1", "model_type": "wanx"}, "remain_fp_regex": "text_embedding|time_embedding|time_projection|head\\.head",
+            "weight": {"n_bits": 8, "sym": False}, "act": {"n_bits": 8, "sym": True}}
+    torch.manual_seed(0)
+    with torch.device(DEV):
+        fp = WanModel(dim=256, ffn_dim=512, num_heads=2, num_layers=1, text_dim=64, freq_dim=64).eval()
+    full = {"qk": {"n_bits": 8, "sym": True}, "v": {"n_bits": 8, "sym": True}, "attn_map": {"n_bits": 8, "sym": False, "group": "row"}}
+    m = QuantWanModel.from_float(fp, qcfg.create(dict(base, attn=full)))
+    m.quant_layer_refactor()
+    m.set_init_done()
+    m.hardware_forward_refactor()
+    b0 = m.hip_blocks[0]
+    assert b0.attn_qk8 and b0.attn_v_bits == 8 and b0.attn_map == (8, False) and b0.cross_attn_map is None
+    lat = torch.randn(16, 2, 8, 6, device=DEV)
+    y = m([lat], torch.tensor([300], device=DEV), [torch.randn(16, 64, device=DEV) * 0.1], 24)[0]
+    assert torch.isfinite(y).all()
+
+
 def test_attention_map_quant_ignores_padded_query_rows():
     """with a padded sequence (rows >= q_len are padding, e.g. the last rank's tail under Ulysses) a key column's
     quantisation step must come from the REAL queries only, as in the reference, whose map has no padding rows.  The padded

@@ -240,3 +240,24 @@ def test_a16_attention_map_quantiser_vs_reference(golden, tag, bits, sym):
     # at a .5 boundary, i.e. by one step of a column whose maximum is <= 1
     assert (x - ref).abs().max().item() < 2.0 / (2 ** (bits - 1) - 1) * v.abs().max().item()
     assert ((x - ref).norm() / ref.norm()).item() < 2e-3
+
+
+@pytest.mark.parametrize("tag,bits,sym", [("8a", 8, False), ("8s", 8, True), ("4s", 4, True)])
+def test_a16_full_quantised_attention_recipe_vs_reference(golden, tag, bits, sym):
+    """The reference's WHOLE quantised-attention recipe (W/models/quant_opensora.py:431-476): its q / k / v DynamicQuantizers with
+    the reshapes of :431-440, the map of the quantised q and k, its attention-map quantiser, `attn @ v` with the quantised v --
+    against the oracle's composition of qk_fake_quant / v_fake_quant / attention_map_quant (the form BlockRef evaluates when
+    attn.qk, attn.v and attn.attn_map are all configured).  Fixture: tests/golden/make_golden_attn_map.py, keys full_*."""
+    import torch
+
+    from oracle import wan_ref as wr
+
+    g = golden("a16_attn_map")
+    q, k, v = (torch.from_numpy(g[n])[0].permute(1, 0, 2).contiguous() for n in ("q", "k", "v"))  # [N, H, D]
+    q8, k8, v8 = wr.qk_fake_quant(q, 8), wr.qk_fake_quant(k, 8), wr.v_fake_quant(v, 8)
+    for name, ours in (("full_q8", q8), ("full_k8", k8), ("full_v8", v8)):
+        assert torch.equal(ours, torch.from_numpy(g[name])[0].permute(1, 0, 2)), name  # the three quantisers: bit for bit
+    x = wr.attention_map_quant(q8, k8, v8, None, bits, sym)
+    ref = torch.from_numpy(g[f"full_x_{tag}"])[0].permute(1, 0, 2)
+    assert (x - ref).abs().max().item() < 2.0 / (2 ** (bits - 1) - 1) * v.abs().max().item()
+    assert ((x - ref).norm() / ref.norm()).item() < 2e-3

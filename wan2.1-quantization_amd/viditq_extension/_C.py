@@ -53,6 +53,8 @@ PROTOTYPES = {
     "wanq_attention_split_workspace": [_i64, _i, _i, _i],
     "wanq_attention_map_workspace": [_i64, _i64, _i],
     "wanq_attention_map_quant_fwd": [_vp, _vp, _vp, _vp, _i, _i64, _i64, _i, _i, _i64, _i64, _i64, _i64, _f, _i, _i, _vp, _i64, _vp],
+    "wanq_attention_map_quant_qk8_fwd": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i, _i64, _i64, _i, _i, _i64, _i64, _i64, _i64, _f, _i, _i,
+                                         _vp, _i64, _vp],
 }
 for _name, _args in PROTOTYPES.items():
     _fn = getattr(lib, _name)  # AttributeError here = header and library out of sync

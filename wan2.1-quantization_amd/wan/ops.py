@@ -146,6 +146,8 @@ def attention_map_quant(q, k, v, num_heads, n_bits=8, sym=False, k_len=None, out
     q [Lq, C], k / v [Lk, C] bf16 -> [Lq, C].  q_len: number of REAL query rows (the rest is sequence padding): a column's
     quantisation step is taken over the real queries only, as the reference's map holds no padding rows; padded output rows
     are zero."""
+    if isinstance(q, Q8Rows):  # the reference's full recipe: int8 q / k (attn.qk) under the map quantiser
+        return _attention_map_quant_q8(q, k, v, num_heads, n_bits, sym, k_len, out, q_len)
     if q_len is not None and int(q_len) < q.shape[0]:
         n = int(q_len)
         if out is None:
@@ -172,6 +174,34 @@ def attention_map_quant(q, k, v, num_heads, n_bits=8, sym=False, k_len=None, out
         _C.call("wanq_attention_map_quant_fwd", _C.ptr(q), _C.ptr(k), _C.ptr(v), _C.ptr(out), _C.dt(q), Lq, Lk, num_heads, d,
                 q.stride(0), k.stride(0), v.stride(0), out.stride(0), 1.0 / math.sqrt(d), int(n_bits), 1 if sym else 0, _C.ptr(ws),
                 nbytes, _C.stream())
+    return out
+
+
+def _attention_map_quant_q8(q8, k8, v, num_heads, n_bits, sym, k_len, out, q_len):
+    """attention_map_quant with q and k as Q8Rows (per-(token, head) int8 codes + scale planes): S runs on the int8 matrix cores
+    in all three passes -- together with a fake-quantised v the reference's whole recipe (W/models/quant_opensora.py:431-476)."""
+    if not isinstance(k8, Q8Rows):
+        raise RuntimeError("attention_map_quant: q and k must both be Q8Rows or both be bf16 tensors")
+    rows, C = q8.codes.shape
+    Lq = rows if q_len is None else min(int(q_len), rows)
+    d = C // num_heads
+    _C.check_gpu("v", v)
+    _C.check_dtype("v", v, torch.bfloat16)
+    if v.dim() != 2 or v.shape[1] != C or v.stride(1) != 1 or v.shape[0] != k8.codes.shape[0]:
+        raise RuntimeError(f"Tensor v must be [{k8.codes.shape[0]}, {C}] with unit column stride")
+    Lk = k8.codes.shape[0] if k_len is None else min(int(k_len), k8.codes.shape[0])
+    if out is None:
+        out = torch.empty(rows, C, dtype=torch.bfloat16, device=v.device)
+    if Lq < rows:
+        out[Lq:].zero_()  # padding rows of the sequence: not queries of the map (see attention_map_quant)
+    if Lq == 0:
+        return out
+    nbytes = _C.lib.wanq_attention_map_workspace(Lq, Lk, num_heads)
+    ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=v.device)
+    with torch.cuda.device(v.device):
+        _C.call("wanq_attention_map_quant_qk8_fwd", _C.ptr(q8.codes), _C.ptr(q8.scales), q8.stride, _C.ptr(k8.codes), _C.ptr(k8.scales),
+                k8.stride, _C.ptr(v), _C.ptr(out), _C.BF16, Lq, Lk, num_heads, d, q8.codes.stride(0), k8.codes.stride(0), v.stride(0),
+                out.stride(0), 1.0 / math.sqrt(d), int(n_bits), 1 if sym else 0, _C.ptr(ws), nbytes, _C.stream())
     return out
 
 

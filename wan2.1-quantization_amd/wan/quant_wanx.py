@@ -133,8 +133,6 @@ class QuantWanModel(WanModel, QuantModel):
                     raise NotImplementedError(
                         f"{key}.attn_map.group = {am.get('group')!r}: the 'block' mode of the reference is tied to CogVideoX's 13x30x45 grid "
                         "and to per-head reorder tables (Q/base/quant_attn.py:176-236); 'row' is implemented (streamed, csrc/attn_map.hip)")
-                if qk8.get(key) or vb.get(key):
-                    raise NotImplementedError(f"{key}.attn_map together with {key}.qk / {key}.v is not implemented (one attention recipe at a time)")
                 amap[key] = (int(am.get("n_bits", 8)), bool(am.get("sym", False)))
         self.__dict__.pop("_ctx_cache", None)
         self.hip_blocks = nn.ModuleList([WanAttentionBlockWithHipKernel.from_float(

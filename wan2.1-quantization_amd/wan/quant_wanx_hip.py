@@ -387,7 +387,11 @@ class WanAttentionBlockWithHipKernel(nn.Module):
             qc = ops.Q8Rows.from_exchange(wq[0].wait(), wq[1].wait(), d, False)
             kc = ops.Q8Rows.from_exchange(wk[0].wait(), wk[1].wait(), d, True)
             vc = self._vq(wv.wait(), self.attn_v_bits, seq_len)
-            back.append(sp.gather_heads(ops.attention_qk8(qc, kc, vc, (c1 - c0) // d, seq_len), async_op=True, out=o, cols=(c0, c1)))
+            if self.attn_map is not None:
+                oc = ops.attention_map_quant(qc, kc, vc, (c1 - c0) // d, self.attn_map[0], self.attn_map[1], seq_len, q_len=seq_len)
+            else:
+                oc = ops.attention_qk8(qc, kc, vc, (c1 - c0) // d, seq_len)
+            back.append(sp.gather_heads(oc, async_op=True, out=o, cols=(c0, c1)))
         for b in back:
             b.wait()
         return o
@@ -411,7 +415,10 @@ class WanAttentionBlockWithHipKernel(nn.Module):
             q8 = ops.rmsnorm_rope_q8(q, sa.norm_q_weight, rope, d, False, eps=self.eps)
             k8 = ops.rmsnorm_rope_q8(self._linear(sa.k, h), sa.norm_k_weight, rope, d, True, eps=self.eps)
             v = self._vq(self._linear(sa.v, h), self.attn_v_bits, seq_len)
-            o = ops.attention_qk8(q8, k8, v, H, seq_len)
+            if self.attn_map is not None:  # q / k / v quantisers AND the map quantiser: the reference's whole recipe
+                o = ops.attention_map_quant(q8, k8, v, H, self.attn_map[0], self.attn_map[1], seq_len, q_len=seq_len)
+            else:
+                o = ops.attention_qk8(q8, k8, v, H, seq_len)
         elif sp is None or sp.size == 1:
             ops.rmsnorm_rope_(q, sa.norm_q_weight, rope, d, eps=self.eps)
             k = self._linear(sa.k, h)
@@ -460,7 +467,13 @@ class WanAttentionBlockWithHipKernel(nn.Module):
         q = self._linear(ca.q, h)
         k, v = self._context_kv(ctx)
         if self.cross_attn_qk8:
-            o = ops.attention_qk8(ops.rmsnorm_rope_q8(q, ca.norm_q_weight, None, d, False, eps=self.eps), k, v, H)
+            q8 = ops.rmsnorm_rope_q8(q, ca.norm_q_weight, None, d, False, eps=self.eps)
+            if self.cross_attn_map is not None:
+                if sp is not None and sp.size > 1:
+                    raise NotImplementedError("cross_attn.attn_map under sequence parallelism (column statistics span the ranks' token shards)")
+                o = ops.attention_map_quant(q8, k, v, H, self.cross_attn_map[0], self.cross_attn_map[1], q_len=seq_len)
+            else:
+                o = ops.attention_qk8(q8, k, v, H)
         else:
             ops.rmsnorm_rope_(q, ca.norm_q_weight, None, d, eps=self.eps)
             if self.cross_attn_map is not None:
