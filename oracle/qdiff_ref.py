@@ -52,6 +52,35 @@ def dynamic_fake_quant_sym(x, n_bits=8):
     return (q.astype(F32) * delta[:, None]).astype(F32)
 
 
+def dynamic_quant_params_asym(x, n_bits=8):
+    """Per-row (delta, zero_point) of DynamicQuantizer, asymmetric branch.  Q/base/base_quantizer.py:130-149:
+    x_max clipped to >= 0, x_min to <= 0, delta = (x_max - x_min) / (2**b - 1) floored at 1e-8, zp = rne(x_min / delta) + 2**b / 2."""
+    x = np.asarray(x, dtype=F32)
+    assert x.ndim == 2 and not np.isnan(x).any()
+    n_levels = 2 ** n_bits
+    hi = np.maximum(x.max(axis=1), F32(0)).astype(F32)
+    lo = np.minimum(x.min(axis=1), F32(0)).astype(F32)
+    delta = ((hi - lo) / F32(n_levels - 1)).astype(F32)
+    delta = np.where(delta < F32(1e-8), F32(1e-8), delta).astype(F32)
+    zp = (np.round((lo / delta).astype(F32)) + F32(n_levels / 2)).astype(F32)
+    return delta, zp
+
+
+def dynamic_quantize_asym(x, n_bits=8):
+    """x_int = rne(x / delta) - zp clamped to [-2**b - 1, 2**b].  Q/base/base_quantizer.py:154-157.  -> (q int32, delta, zp)."""
+    x = np.asarray(x, dtype=F32)
+    delta, zp = dynamic_quant_params_asym(x, n_bits)
+    n = 2 ** n_bits
+    q = np.clip(np.round((x / delta[:, None]).astype(F32)) - zp[:, None], -n - 1, n)
+    return q.astype(np.int32), delta, zp
+
+
+def dynamic_fake_quant_asym(x, n_bits=8):
+    """DynamicQuantizer.forward, asymmetric: (q + zp) * delta.  Q/base/base_quantizer.py:159-162."""
+    q, delta, zp = dynamic_quantize_asym(x, n_bits)
+    return ((q.astype(F32) + zp[:, None]) * delta[:, None]).astype(F32)
+
+
 # ------------------------------------------------------------------ A1 static per-channel
 def static_quant_params(w, n_bits=8, sym=False):
     """StaticQuantizer.init_quant_params.  Q/base/base_quantizer.py:70-99.

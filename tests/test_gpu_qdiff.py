@@ -486,3 +486,29 @@ def test_quarot_linear_vs_reference_golden(golden):
     assert d.max() <= 1 and (d != 0).mean() < 2e-3
     y = ql(t(g["x"]))
     assert np.abs(y.cpu().numpy() - g["y"]).max() < 5e-3 * np.abs(g["y"]).max() + 1e-3
+
+
+def test_dynamic_quantizer_asymmetric_branch_vs_reference_golden(golden):
+    """qdiff.DynamicQuantizer with sym=False (the branch of Q/base/base_quantizer.py:130-157 no Wan configuration selects) on the
+    HIP row-statistics / static-quantisation kernels: delta, zero point, codes and dequantised values bit for bit against the
+    reference's own module (tests/golden/make_golden_dyn_asym.py), 8 and 4 bits; and a QuantizedLinear with asymmetric
+    activations (int8 GEMM + the zero point's rank-one term) against the reference layer's output."""
+    from qdiff import config as qcfg
+    from qdiff.base.base_quantizer import DynamicQuantizer
+    from qdiff.base.quant_layer import QuantizedLinear
+
+    g = golden("a2_dynamic_asym")
+    x = t(g["x"], torch.float32)
+    for bits in (8, 4):
+        dq = DynamicQuantizer(qcfg.create({"n_bits": bits, "sym": False}))
+        codes = dq.quantize(x)
+        assert np.array_equal(dq.delta.reshape(-1).cpu().numpy(), g[f"delta{bits}"])
+        assert np.array_equal(dq.zero_point.reshape(-1).cpu().numpy(), g[f"zp{bits}"])
+        assert np.array_equal(codes.cpu().numpy().astype(np.int32), np.clip(g[f"q{bits}"], -128, 127))
+        assert np.array_equal(dq(x).cpu().numpy(), g[f"dequant{bits}"])
+    lin = torch.nn.Linear(256, 24).to(DEV)
+    lin.weight.data, lin.bias.data = t(g["w"], torch.float32), t(g["b"], torch.float32)
+    ql = QuantizedLinear(256, 24, True, DEV, qcfg.create({"weight": {"n_bits": 8, "sym": False}, "act": {"n_bits": 8, "sym": False}}), lin)
+    ql.w_quantizer.init_done = True
+    y = ql(x.unsqueeze(0))[0].float().cpu().numpy()
+    assert np.abs(y - g["y"]).max() < 2e-5 * np.abs(g["y"]).max() + 2e-5

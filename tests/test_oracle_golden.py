@@ -261,3 +261,20 @@ def test_a16_full_quantised_attention_recipe_vs_reference(golden, tag, bits, sym
     ref = torch.from_numpy(g[f"full_x_{tag}"])[0].permute(1, 0, 2)
     assert (x - ref).abs().max().item() < 2.0 / (2 ** (bits - 1) - 1) * v.abs().max().item()
     assert ((x - ref).norm() / ref.norm()).item() < 2e-3
+
+
+@pytest.mark.parametrize("bits", [8, 4])
+def test_a2_dynamic_quantizer_asymmetric_branch_vs_reference(golden, bits):
+    """The asymmetric branch of the reference's DynamicQuantizer (base_quantizer.py:130-157; selected by no Wan configuration) on
+    mixed, all-positive, all-negative and exact-tie rows: codes, delta, zero point and the dequantised values, bit for bit; and
+    a QuantizedLinear whose activations use it (x_dq . w_dq^T + b in fp32: summation order only)."""
+    from oracle import qdiff_ref as qr
+
+    g = golden("a2_dynamic_asym")
+    q, delta, zp = qr.dynamic_quantize_asym(g["x"], bits)
+    assert np.array_equal(q, g[f"q{bits}"]) and np.array_equal(delta, g[f"delta{bits}"]) and np.array_equal(zp, g[f"zp{bits}"])
+    assert np.array_equal(qr.dynamic_fake_quant_asym(g["x"], bits), g[f"dequant{bits}"])
+    if bits == 8:
+        wdq = qr.static_fake_quant(g["w"], 8, False)[0]
+        y = qr.dynamic_fake_quant_asym(g["x"], 8).astype(np.float64) @ wdq.astype(np.float64).T + g["b"]
+        assert np.abs(y - g["y"]).max() < 2e-5 * np.abs(g["y"]).max()

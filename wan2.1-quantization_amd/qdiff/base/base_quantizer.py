@@ -76,17 +76,44 @@ class StaticQuantizer(BaseQuantizer):
 
 
 class DynamicQuantizer(BaseQuantizer):
-    """Per-token dynamic quantizer for activations (sym, 8 bit: the only activation format of the Wan configs)."""
+    """Per-group (per-token) dynamic quantizer (base_quantizer.py:101-162).  Symmetric (:116-128; every Wan configuration): one
+    fused HIP pass gives int8 codes, scale and sum.  Asymmetric (:130-149; selected by no Wan configuration, pinned by
+    tests/golden/a2_dynamic_asym.npz): the row minimum / maximum, delta and zero point are those of the static asymmetric
+    quantiser evaluated per call (same equations, eps floor 1e-8), on the same HIP kernels (row_minmax + weight_quant)."""
 
     def _check(self):
-        if not self.sym or self.n_bits != 8:
-            raise NotImplementedError("the HIP activation quantiser implements symmetric 8-bit per-token quantisation")
+        if self.n_bits != 8:
+            raise NotImplementedError("the int8 activation path implements 8-bit per-token quantisation")
+
+    # ---- asymmetric branch ------------------------------------------------------------------------
+    def _asym_params(self, x):
+        lo, hi, _ = fused.row_minmax(x)
+        hi, lo = hi.clamp_min(0.0), lo.clamp_max(0.0)
+        delta = (hi - lo) / _full(hi, self.n_levels - 1)
+        delta = torch.where(delta < 1e-8, _full(delta, 1e-8), delta)  # (the reference drops into ipdb first, then floors: :139-146)
+        zp = torch.round(lo / delta) + self.n_levels / 2
+        self.delta, self.zero_point = delta.unsqueeze(-1), zp.unsqueeze(-1)
+        return delta.contiguous(), zp.contiguous()
+
+    def _asym(self, x, want_codes, want_dequant, lo=None, hi=None):
+        x = x.contiguous().float()
+        delta, zp = self._asym_params(x)
+        n = self.n_levels
+        return fused.weight_quant(x, delta, zp, -n - 1 if lo is None else lo, n if hi is None else hi, want_codes, want_dequant)
 
     def quantize_int8(self, x, premul=None, rotation=None, want_sum=True):
-        """int8 codes + fp32 (scale [T], sum [T]).  premul / rotation = (had_k, hadk): the ViDiT transform fused in."""
+        """int8 codes + fp32 (scale [T], sum [T]).  premul / rotation = (had_k, hadk): the ViDiT transform fused in.
+        Asymmetric: the per-token zero point is left in `self.zero_point`; the caller adds its rank-one term
+        (QuantizedLinear.forward).  int8 storage saturates the code 128 the reference's loose clamp admits at an exact tie (D9)."""
         self._check()
         x = x.contiguous()
         rows = x.shape[0]
+        if not self.sym:
+            if premul is not None or rotation is not None:
+                raise NotImplementedError("asymmetric activations under a ViDiT / QuaRot / SmoothQuant transform are not implemented")
+            codes, _ = self._asym(x, True, False, -128, 127)
+            scale = self.delta.reshape(-1).float().contiguous()
+            return codes, scale, (codes.float().sum(dim=1) * scale) if want_sum else None
         qs = torch.empty(2, rows, dtype=torch.float32, device=x.device)
         if premul is None and rotation is None:
             q = fused.quant_sum(x, qs[1] if want_sum else None, qs[0])
@@ -97,8 +124,14 @@ class DynamicQuantizer(BaseQuantizer):
 
     def quantize(self, x):
         assert x.dim() == 2
+        if not self.sym:  # (8 bits: codes live in int8 storage, which saturates the 2^b-th level of the reference's loose clamp, D9)
+            return self._asym(x, True, False, *((-128, 127) if self.n_bits == 8 else (None, None)))[0].float()
+        self._check()
         return self.quantize_int8(x, want_sum=False)[0].float()
 
     def forward(self, x):
+        if not self.sym:
+            return self._asym(x, False, True)[1]
+        self._check()
         q, scale, _ = self.quantize_int8(x, want_sum=False)
         return q.float() * scale.unsqueeze(-1)

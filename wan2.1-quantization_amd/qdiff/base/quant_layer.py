@@ -131,6 +131,11 @@ class QuantizedLinear(nn.Linear):
         y = qgemm.w8a8_linear(q, self._codes, scale, wq.delta.reshape(-1).float().contiguous(),
                               None if self.bias is None else self.bias.detach().float().contiguous(),
                               ssum if zp is not None else None, zp, out_dtype=out_dtype, w4=w4)
+        if not self.a_quantizer.sym:
+            # asymmetric activations x_dq = (q + zp_a) * s_a: the zero point's share of x_dq . w_dq^T is the rank-one term
+            # (zp_a s_a)[token] x rowsum(w_dq)[channel]  (Q/base/base_quantizer.py:130-162; no Wan configuration uses this branch)
+            t_a = (self.a_quantizer.zero_point.reshape(-1).float() * scale).to(y.dtype)
+            y = torch.addcmul(y, t_a.unsqueeze(1), self.weight.data.float().sum(dim=1).to(y.dtype).unsqueeze(0))
         return y.view(*shape[:-1], self.out_features)
 
     # ---- PTQ hooks shared by the variants ------------------------------------------------------------

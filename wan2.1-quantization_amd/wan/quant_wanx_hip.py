@@ -126,6 +126,9 @@ def _to_hip_linear(lin, n_bits, sym, act_dtype):
 
     if isinstance(lin, QuantizedLinear):
         if lin.quant_mode and lin.w_quantizer is not None and lin.a_quantizer is not None:
+            if not lin.a_quantizer.sym:
+                raise NotImplementedError("kernel mode: the fused producers quantise activations symmetrically per token (every Wan "
+                                          "configuration); asymmetric activations run in simulation mode (qdiff.QuantizedLinear)")
             return HipLinearW8A8.from_quantized(lin)
         lin = lin.fp_module
     if n_bits is None:
