@@ -28,7 +28,7 @@ def main():
         wtr = csv.writer(fh)
         wtr.writerow(["launch", "Lq", "Lk", "heads", "algorithmic_read_MB", "FETCH_SIZE_x2_MB", "algorithmic_write_MB", "WRITE_SIZE_MB"])
         wtr.writerows(rows)
-    summary = {"kernel": "attn_fwd_kernel", "launches": len(LAUNCHES), "hbm_bytes_per_launch": tot_hbm / len(LAUNCHES),
+    summary = {"kernel": "attn_fwd16_kernel<false, false> (the default bf16 kernel; WANQ_ATTN_M16=0 would run attn_fwd_kernel)", "launches": len(LAUNCHES), "hbm_bytes_per_launch": tot_hbm / len(LAUNCHES),
                "algorithmic_bytes_per_launch": tot_alg / len(LAUNCHES),
                # which bench.py workload the launches belong to (bench.py reports the figure only for that workload) and which
                # code they were taken on

@@ -22,7 +22,7 @@ lib = ctypes.CDLL(LIB_PATH)
 
 F16, BF16, F32, I32, I16 = 0, 1, 2, 3, 4
 EPI_GELU, EPI_GATE_RES = 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
