@@ -50,6 +50,7 @@ report("quant bf16 -> int8 [L,1536] (attention output)", timeit(lambda: fused.qu
 report("rotate+quant bf16 -> int8 [L,1536]", timeit(lambda: fused.rotate_quant(xb, pms[0], rot, u_, s_)), L * C * 3)
 hb = torch.randn(L, F, device=DEV, generator=g).to(torch.bfloat16)
 report("quant bf16 -> int8 [L,8960] (GELU output)", timeit(lambda: fused.quant_sum(hb, u_, s_)), L * F * 3)
+report("GELU + quant bf16 -> int8 [L,8960] (ffn.0 pre-activation -> ffn.2 input: the step's form)", timeit(lambda: fused.gelu_quant_sum(hb, u_, s_)), L * F * 3)
 rot_f = qu.kernel_rotation_params(F, DEV)
 pm_f = torch.randn(F, device=DEV, generator=g)
 qf = None

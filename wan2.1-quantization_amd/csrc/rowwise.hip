@@ -413,6 +413,83 @@ __global__ __launch_bounds__(256) void weight_quant_kernel(const void* w, int dt
 
 // x * premul (-> LayerNorm + modulate first when `ln`) -> fp output and / or int8 quantise: the transform entry points of
 // rotate.hip with had_k == 0 (channel scale without rotation: SmoothQuant, Q/smooth_quant/sq_quant_layer.py:52-60).
+// ------------------------------------------------------------------------------ wide 16-bit rows: one WAVE per row
+// The FFN hidden of the 1.3B model ([L, 8960] bf16 -> int8, with or without the tanh-GELU: quant_sum / gelu_quant_sum) through
+// the general kernel is four waves per row, two workgroup barriers per row (row maximum, integer sum), five chunk slots per
+// lane of which the row fills 4.4, and a control-flow graph that carries every option of the general entry: 26 vector
+// instructions per element (profiles/r03_h_rowwise_sq.csv) for a job that needs about ten.  Here a wave owns a row: NCH
+// 16-byte chunks per lane (chunk lane + 64 i), all requested up front, the row kept in registers, both reductions inside
+// the wave (DPP / permlane swaps: no LDS, no barrier), one dtype per instantiation, no other options.  Bit-identical
+// outputs (same operations per element, same reduction tree per wave; the cross-wave LDS step of the general kernel is a
+// max / an integer sum).
+template <typename T, int NCH, bool GELU>
+__global__ __launch_bounds__(256, 2) void quant_rows_wave_kernel(const void* x, int8_t* q, void* scale_out, void* sum_out, int vec_dtype,
+                                                                 int64_t rows, int cols) {
+  static_assert(NCH % 2 == 0, "chunks are owned in pairs");
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;  // whole wave (no barriers in this kernel)
+  const int64_t rbase = row * (int64_t)cols;
+  const int last = cols / 8 - 1;  // last valid chunk
+  // a lane owns PAIRS of adjacent chunks (pair lane + 64 h = chunks 2 pair, 2 pair + 1): 32 contiguous input bytes and, for the
+  // codes, ONE 16-byte store per pair (8-byte stores run at about half the rate per byte)
+  float v[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = 2 * (lane + 64 * (i >> 1)) + (i & 1);
+    Io<T>::load8(x, rbase + (int64_t)(ch <= last ? ch : last) * 8, v[i]);  // (a lane past the row end re-reads the last chunk)
+  }
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const bool ok = 2 * (lane + 64 * (i >> 1)) + (i & 1) <= last;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = GELU ? gelu_tanh_fast_f32(v[i][j]) : v[i][j];
+      t = ok ? t : 0.f;
+      v[i][j] = t;
+      m = fmaxf(m, fabsf(t));
+    }
+  }
+  const float amax = wave_max(m);
+  float scale = amax / 127.0f;
+  if (scale < 1e-6f) scale = 1e-6f;  // qdiff eps rule (base_quantizer.py:122-127)
+  const float inv = 1.0f / scale;
+  int isum = 0;
+#pragma unroll
+  for (int h = 0; h < NCH / 2; ++h) {
+    uint32_t pa[2], pb[2];
+    quantN_pack_rne<8>(v[2 * h], scale, inv, pa);
+    quantN_pack_rne<8>(v[2 * h + 1], scale, inv, pb);
+    isum = __builtin_amdgcn_sdot4((int)pa[0], 0x01010101, isum, false);
+    isum = __builtin_amdgcn_sdot4((int)pa[1], 0x01010101, isum, false);
+    isum = __builtin_amdgcn_sdot4((int)pb[0], 0x01010101, isum, false);
+    isum = __builtin_amdgcn_sdot4((int)pb[1], 0x01010101, isum, false);
+    const int ch = 2 * (lane + 64 * h);
+    int8_t* dst = q + rbase + (int64_t)ch * 8;
+    if (ch + 1 <= last) *reinterpret_cast<uint4*>(dst) = make_uint4(pa[0], pa[1], pb[0], pb[1]);
+    else if (ch <= last) *reinterpret_cast<uint2*>(dst) = make_uint2(pa[0], pa[1]);
+  }
+  if (sum_out) {
+    const int tot = wave_sum(isum);
+    if (lane == 0) vec_store(sum_out, vec_dtype, row, (float)tot * scale);
+  }
+  if (lane == 0) vec_store(scale_out, vec_dtype, row, scale);
+}
+
+// cols in (8704, 9216] (the 1.3B FFN width 8960 = 17.5 chunks per lane): NCH = 18
+static bool launch_quant_rows_wave(const void* x, int x_dtype, int8_t* q, void* scale, void* sum, int vec_dtype, int64_t rows, int cols, int act,
+                                   hipStream_t st) {
+  static const bool off = getenv("WANQ_QUANT_WAVE_OFF") != nullptr;
+  if (off || cols <= 8704 || cols > 9216 || (x_dtype != WANQ_BF16 && x_dtype != WANQ_F16)) return false;
+  const dim3 grid((unsigned)((rows + 3) / 4));
+#define WANQ_QW(T, G) hipLaunchKernelGGL((quant_rows_wave_kernel<T, 18, G>), grid, dim3(256), 0, st, x, q, scale, sum, vec_dtype, rows, cols)
+  if (x_dtype == WANQ_BF16) { if (act) WANQ_QW(BF16, true); else WANQ_QW(BF16, false); }
+  else { if (act) WANQ_QW(F16, true); else WANQ_QW(F16, false); }
+#undef WANQ_QW
+  return true;
+}
+
 int premul_quant_rows(bool ln, const void* x, int x_dtype, const void* gamma, const void* mshift, const void* mscale,
                       int64_t mod_stride, int64_t rows_per_batch, float eps, const float* premul, void* out_fp, int out_dtype,
                       int8_t* q, void* scale, void* sum, int vec_dtype, int64_t rows, int cols, hipStream_t st, const char* what) {
@@ -476,6 +553,8 @@ extern "C" int wanq_quant_rows(const void* x, int x_dtype, int8_t* q, void* scal
   WANQ_REQUIRE(act == 0 || act == 1, WANQ_E_ARG, "wanq_quant_rows: act must be 0 or 1");
   if (int e = check_rows_cols("wanq_quant_rows", rows, cols)) return e;
   if (rows == 0) return WANQ_OK;
+  if (!static_amax && launch_quant_rows_wave(x, x_dtype, q, scale, sum, vec_dtype, rows, cols, act, (hipStream_t)stream))
+    return check_launch("wanq_quant_rows");
   RowParams p{};
   p.x = x; p.x_dtype = x_dtype; p.q = q; p.scale = scale; p.sum = sum; p.vec_dtype = vec_dtype;
   p.rows = rows; p.cols = cols; p.act = act; p.static_amax = static_amax; p.rows_per_batch = 1;
