@@ -667,6 +667,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define WANQ_ATTN_DMA_LATE 0
 #endif
 // timing-only ablations (wrong results; tools/probes/README.md): skip the lazy-rescale vote after the first tile / replace v_exp
+#ifndef WANQ_ABL_NODMA  // timing ablation (wrong results): no K / V tile is fetched inside the tile loop
+#define WANQ_ABL_NODMA 0
+#endif
 #ifndef WANQ_ABL_NOMAX
 #define WANQ_ABL_NOMAX 0
 #endif
@@ -850,7 +853,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
     if (j >= jt1) break;
     const char* sK = smem + u * STAGE;
     asm volatile("" : "+v"(d_k0), "+v"(d_k1), "+v"(d_k2), "+v"(d_k3), "+v"(d_v0), "+v"(d_v1), "+v"(d_v2), "+v"(d_v3));
-    if (!((WANQ_ATTN_DMA_LATE != 0) && (WANQ_ATTN_KASM != 0) && !QK8) && j + 2 < jt1) A16_DMA(j + 2, (u + 2) % 3);
+    if (!((WANQ_ATTN_DMA_LATE != 0) && (WANQ_ATTN_KASM != 0) && !QK8) && !WANQ_ABL_NODMA && j + 2 < jt1) A16_DMA(j + 2, (u + 2) % 3);
 
     // ---------------- S^T blocks: fragment i = 4 kb + s read four ahead of its two MFMAs
     f32x4 sacc[4][2];
@@ -865,7 +868,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
 #define A16_KR(i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[i]) : "v"(((i) & 3) == 0 ? ka0 : ((i) & 3) == 1 ? ka1 : ((i) & 3) == 2 ? ka2 : ka3), "n"(((i) >> 2) * 4096))
 #pragma unroll
       for (int i = 0; i < KA; ++i) { A16_KR(i); }
-      if (WANQ_ATTN_DMA_LATE && j + 2 < jt1) A16_DMA(j + 2, (u + 2) % 3);  // the first fragments fly under the DMA issue
+      if (WANQ_ATTN_DMA_LATE && !WANQ_ABL_NODMA && j + 2 < jt1) A16_DMA(j + 2, (u + 2) % 3);  // the first fragments fly under the DMA issue
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         if (i + KA < 16) { A16_KR(i + KA); }
