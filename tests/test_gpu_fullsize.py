@@ -154,3 +154,67 @@ def test_config4_per_rank_attention_5_heads_75600_keys():
     ref = (torch.softmax(qs @ kk.transpose(1, 2) / 128 ** 0.5, dim=-1) @ vv).transpose(0, 1).reshape(len(rows), HR * 128)
     got = o[rows].float()
     assert float((got - ref).abs().max()) < 3e-2 and float((got - ref).norm() / ref.norm()) < 1e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The attention-map quantiser at the headline size.  Its column parameters are statistics over ALL 32760 queries
+# of a head, so the small-size oracle comparisons (tests/test_gpu_attn_qk8.py, Lq <= 1000) say nothing about 512-tile rings, the
+# ragged last tile (32760 = 511 x 64 + 56) or 128 workgroups per head meeting in the column-maximum atomics.
+def _column_maxima_and_rows(qf, kf, rows, chunk=4096):
+    """fp32 definition, streamed: per (head, key) maximum of softmax(q k^T / sqrt(d)) over all queries, and the map rows of the
+    sampled queries.  qf [Lq, H, d], kf [Lk, H, d] fp32 on the GPU -> colmax [H, Lk], p_rows [H, S, Lk]."""
+    Lq, Hn, d = qf.shape
+    kt = kf.permute(1, 2, 0).contiguous()  # [H, d, Lk]
+    colmax = torch.zeros(Hn, kf.shape[0], device=qf.device)
+    for a in range(0, Lq, chunk):
+        p = torch.softmax(qf[a:a + chunk].transpose(0, 1) @ kt / d ** 0.5, dim=-1)  # [H, c, Lk]
+        colmax = torch.maximum(colmax, p.amax(dim=1))
+        del p
+    p_rows = torch.softmax(qf[rows].transpose(0, 1) @ kt / d ** 0.5, dim=-1)
+    return colmax, p_rows
+
+
+@pytest.mark.parametrize("form,sym", [("bf16", False), ("qk8", False), ("bf16", True)])
+def test_attention_map_quant_full_size_sampled_queries(form, sym):
+    """wanq_attention_map_quant_fwd / _qk8_fwd at L = 32760 x 12 heads against the oracle's column quantiser
+    (oracle/wan_ref.py::attn_map_fake_quant, pinned by the reference's QuantizedAttentionMapOpenSORA) on sampled query rows.  The
+    oracle function is given the sampled rows of the fp32 map plus one row holding the streamed column maxima, so its column
+    parameters are those of the whole map (softmax values are >= 0: the clamped column minimum is 0 either way)."""
+    from oracle import wan_ref as wr
+    from viditq_extension import fused
+    from wan import ops
+
+    d, bits = 128, 8
+    g = torch.Generator(device=DEV).manual_seed(11)
+    q = (torch.randn(L, H * d, device=DEV, generator=g) * 1.5).to(torch.bfloat16)
+    k = (torch.randn(L, H * d, device=DEV, generator=g) * 1.5).to(torch.bfloat16)
+    v = torch.randn(L, H * d, device=DEV, generator=g).to(torch.bfloat16)
+    k[69] *= 3.0  # a dominant key column
+    rows = torch.from_numpy(np.unique(np.concatenate([np.random.default_rng(5).integers(0, L, 40), [0, 255, 256, L - 57, L - 1]]))).to(DEV)
+    if form == "qk8":
+        ident = torch.zeros(L, d // 2, 2, device=DEV)
+        ident[..., 0] = 1.0  # rotary = identity, no RMSNorm weight: the kernel only quantises
+        q8, k8 = ops.rmsnorm_rope_q8(q, None, ident, d, False), ops.rmsnorm_rope_q8(k, None, ident, d, True)
+        qf = q8.codes.float().view(L, H, d) * q8.scales[0, :, :L].t().unsqueeze(-1)  # the dequantised operands (codes bit-exact by
+        kf = k8.codes.float().view(L, H, d) * k8.scales[0, :, :L].t().unsqueeze(-1)  # tests/test_gpu_attn_qk8.py)
+        vd = v.clone()
+        fused.fake_quant_cols_(vd, 8)  # attn.v of the full recipe (bit-exact by its own golden test)
+        out = ops.attention_map_quant(q8, k8, vd, H, bits, sym)
+    else:
+        qf, kf, vd = q.float().view(L, H, d), k.float().view(L, H, d), v
+        out = ops.attention_map_quant(q, k, v, H, bits, sym)
+    assert out.shape == (L, H * d) and bool(torch.isfinite(out.float()).all())
+    colmax, p_rows = _column_maxima_and_rows(qf, kf, rows)
+    S = len(rows)
+    pq = wr.attn_map_fake_quant(torch.cat([p_rows, colmax[:, None, :]], dim=1), bits, sym)[:, :S]  # [H, S, Lk]
+    vv = vd.float().view(L, H, d).transpose(0, 1)                                                   # [H, Lk, d]
+    ref = (pq @ vv).transpose(0, 1).reshape(S, H * d)
+    fp = (p_rows @ vv).transpose(0, 1).reshape(S, H * d)
+    got = out[rows].float()
+    levels = (2 ** (bits - 1) - 1) if sym else (2 ** bits - 1)
+    step = float(colmax.max()) / levels * float(vd.float().abs().max())  # one code of the widest column
+    err, noise = float((got - ref).norm() / ref.norm()), float((ref - fp).norm() / fp.norm())
+    # bar: the small-size test's (P~ goes to the P.V MFMA as bf16; a code may flip at a .5 boundary because the GPU recomputes the
+    # map exp2-based), and well inside the recipe's own distance from FP attention
+    assert float((got - ref).abs().max()) < 3e-2 + 1.5 * step, float((got - ref).abs().max())
+    assert err < 1.2e-2 and err < 0.5 * noise, (err, noise)  # measured: 6.4e-3 against a recipe noise of 2.2e-2 (bf16, asymmetric)
