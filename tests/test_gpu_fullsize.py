@@ -218,3 +218,58 @@ def test_attention_map_quant_full_size_sampled_queries(form, sym):
     # map exp2-based), and well inside the recipe's own distance from FP attention
     assert float((got - ref).abs().max()) < 3e-2 + 1.5 * step, float((got - ref).abs().max())
     assert err < 1.2e-2 and err < 0.5 * noise, (err, noise)  # measured: 6.4e-3 against a recipe noise of 2.2e-2 (bf16, asymmetric)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The two row-wise kernels of the headline step that the tests above do not reach at L = 32760: the q / k / v transform
+# (LayerNorm + modulation, three channel masks, Hadamard rotation, per-token int8: rotate_kernel<12, ..., LN, MULTI>) and the
+# FFN's GELU + quantise (quant_rows_wave_kernel, one wave per [8960] row).
+def test_qkv_transform_full_size_sampled_rows():
+    import viditq_extension.fused as fused
+    from oracle import qdiff_ref as qr
+    from qdiff.quarot import quarot_utils as qu
+
+    g = torch.Generator(device=DEV).manual_seed(1536)
+    x = torch.randn(L, C, device=DEV, generator=g) * 2 + 0.1
+    x[:, 7] *= 20.0  # an outlier channel, as the synthetic model has them
+    sh, sc = torch.randn(1, C, device=DEV, generator=g) * 0.2, torch.randn(1, C, device=DEV, generator=g) * 0.2
+    pms = [(torch.rand(C, device=DEV, generator=g) + 0.5) * (torch.randint(0, 2, (C,), device=DEV, generator=g) * 2 - 1).float() for _ in range(3)]
+    rot = qu.kernel_rotation_params(C, DEV)
+    qs = [torch.empty(L, C, dtype=torch.int8, device=DEV) for _ in range(3)]
+    scales, sums = [torch.zeros(L, device=DEV) for _ in range(3)], [torch.zeros(L, device=DEV) for _ in range(3)]
+    fused.layernorm_rotate_quant_multi(qs, x, None, sh, sc, pms, rot, sums, scales, 1e-6)
+    rows = np.unique(np.concatenate([np.random.default_rng(4).integers(0, L, 40), [0, 1, L - 2, L - 1]]))
+    h = kr.layernorm_t2i(x[rows].cpu().numpy(), None, sh.cpu().numpy(), sc.cpu().numpy(), 1e-6, len(rows))
+    for i in range(3):
+        # whole output: the codes reach +-127 in every row and the row sums are those of the codes
+        qi = qs[i].to(torch.int32)
+        assert bool((qi.abs().amax(1) == 127).all())
+        np.testing.assert_allclose(sums[i].cpu().numpy(), qi.sum(1).cpu().numpy().astype(np.float64) * scales[i].cpu().numpy().astype(np.float64),
+                                   rtol=1e-6, atol=1e-6)
+        # sampled rows: the oracle's fp64 rotation of the fp64 LayerNorm (the kernel's transform is fp32: a code moves only at a .5 tie)
+        ref = qr.matmul_hadU(h * pms[i].double().cpu().numpy()).astype(np.float32)
+        oq, oscale = qr.dynamic_quantize_sym(ref)
+        np.testing.assert_allclose(scales[i][rows].cpu().numpy(), oscale, rtol=1e-5)
+        d = np.abs(qs[i][rows].cpu().numpy().astype(np.int32) - oq)
+        assert d.max() <= 1 and (d != 0).mean() < 3e-3, (d.max(), (d != 0).mean())
+
+
+def test_gelu_quantise_full_size_sampled_rows():
+    import viditq_extension.fused as fused
+
+    g = torch.Generator(device=DEV).manual_seed(8960)
+    x = (torch.randn(L, F, device=DEV, generator=g) * torch.exp(0.5 * torch.randn(F, device=DEV, generator=g))).to(torch.bfloat16)
+    x[17] = 0  # GELU(0) = 0: the eps branch
+    scale, ssum = torch.zeros(L, device=DEV), torch.zeros(L, device=DEV)
+    q = fused.gelu_quant_sum(x, ssum, scale)
+    qi = q.to(torch.int32)
+    live = torch.ones(L, dtype=torch.bool, device=DEV)
+    live[17] = False
+    assert bool((qi.abs().amax(1)[live] == 127).all()) and int(qi[17].abs().max()) == 0 and scale[17].item() == pytest.approx(1e-6)
+    np.testing.assert_allclose(ssum.cpu().numpy(), qi.sum(1).cpu().numpy().astype(np.float64) * scale.cpu().numpy().astype(np.float64), rtol=1e-6, atol=1e-6)
+    rows = np.unique(np.concatenate([np.random.default_rng(6).integers(0, L, 40), [0, 16, 17, 18, L - 1]]))
+    oq, oscale, _ = kr.gelu_quant_sum(x[rows].float().cpu().numpy())
+    # the kernel's GELU is the exp / rcp form (relative error < 3e-6 against tanhf): scales to 1e-5, codes move at ties
+    np.testing.assert_allclose(scale[rows].cpu().numpy(), oscale, rtol=1e-5)
+    d = np.abs(q[rows].cpu().numpy().astype(np.int32) - oq.astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3, (d.max(), (d != 0).mean())
