@@ -273,3 +273,91 @@ def test_gelu_quantise_full_size_sampled_rows():
     np.testing.assert_allclose(scale[rows].cpu().numpy(), oscale, rtol=1e-5)
     d = np.abs(q[rows].cpu().numpy().astype(np.int32) - oq.astype(np.int32))
     assert d.max() <= 1 and (d != 0).mean() < 2e-3, (d.max(), (d != 0).mean())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The GEMM's fused epilogues at the headline shapes (the accumulator test above stores raw int32): the 16-bit store loop, the
+# GELU form, and the fp32 + gate + residual form that rewrites the residual stream IN PLACE with its lines prefetched by LDS-DMA
+# (the path whose missing barrier once survived every small test).  Whole output against an fp64 evaluation of the
+# epilogue formula on the exact integer product (int8 values and their dot products are exact in fp64), sampled rows against the
+# oracle's left-to-right fp32 evaluation (K/csrc/qgemm/w8a8/w8a8_gemm_cuda.cu:416-441).
+@pytest.mark.parametrize("N,K,form", [(C, C, "bf16"), (F, C, "bf16_gelu"), (C, C, "f32_gate_res"), (C, F, "f32_gate_res")])
+def test_gemm_epilogues_full_size_whole_output(N, K, form):
+    import viditq_extension.qgemm as qgemm
+
+    g = torch.Generator(device=DEV).manual_seed(N * 3 + K)
+    a, w = _rand_i8((L, K), 5), _rand_i8((N, K), 6)
+    sa = torch.rand(L, device=DEV, generator=g) * 0.02 + 1e-3
+    asum = a.float().sum(1) * sa
+    sw = torch.rand(N, device=DEV, generator=g) * 0.01 + 1e-4
+    zp = torch.randint(-20, 140, (N,), device=DEV, generator=g).float()
+    bias = torch.randn(N, device=DEV, generator=g)
+    acc64 = a.double() @ w.double().t()  # exact
+    y64 = acc64 * sa.double()[:, None] * sw.double()[None, :] + asum.double()[:, None] * (zp.double() * sw.double())[None, :] + bias.double()[None, :]
+    del acc64
+    rows = np.unique(np.concatenate([np.random.default_rng(9).integers(0, L, 24), [0, 255, 256, L - 249, L - 1]]))
+    yo = kr.w8a8_epilogue(kr.w8a8_o32(a[rows].cpu().numpy(), w.cpu().numpy()), sa[rows].cpu().numpy(), sw.cpu().numpy(), bias.cpu().numpy(),
+                          asum[rows].cpu().numpy(), zp.cpu().numpy())
+    if form == "f32_gate_res":
+        gate = torch.randn(N, device=DEV, generator=g)
+        x = torch.randn(L, N, device=DEV, generator=g)
+        want = x.double() + y64 * gate.double()[None, :]
+        xo = x[rows].cpu().numpy()
+        out = qgemm.w8a8_linear(a, w, sa, sw, bias, asum, zp, out_dtype=torch.float32, gate=gate, residual=x, out=x)  # in place
+        assert out.data_ptr() == x.data_ptr()
+        scale = float(want.abs().max())
+        assert float((out.double() - want).abs().max()) < 4e-6 * scale  # a few fp32 roundings of values up to `scale`
+        np.testing.assert_allclose(out[rows].cpu().numpy(), xo + yo * gate.cpu().numpy()[None, :], rtol=0, atol=4e-6 * scale)
+    else:
+        gelu = form == "bf16_gelu"
+        out = qgemm.w8a8_linear(a, w, sa, sw, bias, asum, zp, out_dtype=torch.bfloat16, gelu=gelu)
+        want = torch.nn.functional.gelu(y64, approximate="tanh") if gelu else y64
+        scale = float(want.abs().max())
+        # one bf16 rounding (2^-9 relative) on top of the fp32 epilogue
+        err = (out.double() - want).abs()
+        assert float((err - want.abs() * 2.0 ** -8).max()) < 4e-6 * scale, float(err.max())
+        ref = kr.gelu_tanh(yo) if gelu else yo
+        np.testing.assert_allclose(out[rows].float().cpu().numpy(), ref, rtol=2.0 ** -8, atol=4e-6 * scale)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RMSNorm + RoPE over the headline latent grid (21 x 30 x 52 = 32760 positions) and the cross-attention launch (32760 queries x
+# 512 text keys, with and without key masking): whole outputs against the oracle's definitions evaluated on the GPU in fp32 /
+# fp64 (oracle/wan_ref.py is plain torch: the same functions the small-size tests call on the CPU).
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_rmsnorm_rope_full_size_whole_output(dtype):
+    from oracle import wan_ref as wr
+    from wan import ops
+
+    d, grid = 128, (21, 30, 52)
+    assert grid[0] * grid[1] * grid[2] == L
+    g = torch.Generator(device=DEV).manual_seed(21)
+    x = (torch.randn(L, C, device=DEV, generator=g) * 1.7).to(dtype)
+    w = torch.rand(C, device=DEV, generator=g) + 0.5
+    freqs = wr.rope_freqs(d)
+    table = ops.rope_table(freqs, grid, DEV)
+    assert table.shape == (L, d // 2, 2)
+    ref = wr.rope_apply(wr.rms_norm(x.float(), w, 1e-6).view(L, H, d), grid, freqs.to(DEV)).reshape(L, C)
+    y = ops.rmsnorm_rope_(x.clone(), w, table, d, eps=1e-6)
+    if dtype == torch.bfloat16:  # one bf16 rounding of the result
+        assert float(((y.float() - ref).abs() - ref.abs() * 2.0 ** -8).max()) < 1e-5
+    else:
+        assert float((y - ref).abs().max()) < 4e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("k_len", [512, 77])
+def test_cross_attention_full_size_whole_output(k_len):
+    from wan import ops
+
+    d, Lc = 128, 512
+    g = torch.Generator(device=DEV).manual_seed(512 + k_len)
+    q = torch.randn(L, H * d, device=DEV, generator=g).to(torch.bfloat16)
+    k = torch.randn(Lc, H * d, device=DEV, generator=g).to(torch.bfloat16)
+    v = torch.randn(Lc, H * d, device=DEV, generator=g).to(torch.bfloat16)
+    o = ops.attention(q, k, v, H, k_len=None if k_len == Lc else k_len)
+    qs = q.float().view(L, H, d).transpose(0, 1)                                   # [H, L, d]
+    kk, vv = k[:k_len].float().view(k_len, H, d).transpose(0, 1), v[:k_len].float().view(k_len, H, d).transpose(0, 1)
+    ref = (torch.softmax(qs @ kk.transpose(1, 2) / d ** 0.5, dim=-1) @ vv).transpose(0, 1).reshape(L, H * d)
+    got = o.float()
+    assert bool(torch.isfinite(got).all())
+    assert float((got - ref).abs().max()) < 3e-2 and float((got - ref).norm() / ref.norm()) < 1e-2  # the flash-attention bar (bf16 P, bf16 O)
