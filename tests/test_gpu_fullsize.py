@@ -206,7 +206,7 @@ def test_attention_map_quant_full_size_sampled_queries(form, sym):
     assert out.shape == (L, H * d) and bool(torch.isfinite(out.float()).all())
     colmax, p_rows = _column_maxima_and_rows(qf, kf, rows)
     S = len(rows)
-    pq = wr.attn_map_fake_quant(torch.cat([p_rows, colmax[:, None, :]], dim=1), bits, sym)[:, :S]  # [H, S, Lk]
+    pq = wr.attn_map_fake_quant(torch.cat([p_rows, colmax[:, None, :]], dim=1).cpu(), bits, sym)[:, :S].to(DEV)  # [H, S, Lk]; the oracle on the CPU
     vv = vd.float().view(L, H, d).transpose(0, 1)                                                   # [H, Lk, d]
     ref = (pq @ vv).transpose(0, 1).reshape(S, H * d)
     fp = (p_rows @ vv).transpose(0, 1).reshape(S, H * d)
@@ -361,3 +361,97 @@ def test_cross_attention_full_size_whole_output(k_len):
     got = o.float()
     assert bool(torch.isfinite(got).all())
     assert float((got - ref).abs().max()) < 3e-2 and float((got - ref).norm() / ref.norm()) < 1e-2  # the flash-attention bar (bf16 P, bf16 O)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The remaining row-wise / column-wise kernels of the step and of the calibration pass at L = 32760.
+def test_layernorm_modulate_quant_full_size_sampled_rows():
+    """norm3 / norm2 -> quantise ([32760, 1536] fp32 residual stream -> int8 + scale + sum): rowwise_kernel<..., LN>."""
+    import viditq_extension.fused as fused
+
+    g = torch.Generator(device=DEV).manual_seed(77)
+    x = torch.randn(L, C, device=DEV, generator=g) * 2 + 0.3
+    x[:, 11] *= 25.0
+    w = torch.randn(C, device=DEV, generator=g)
+    sh, sc = torch.randn(1, C, device=DEV, generator=g) * 0.3, torch.randn(1, C, device=DEV, generator=g) * 0.3
+    q = torch.empty(L, C, dtype=torch.int8, device=DEV)
+    scale, ssum = torch.zeros(L, device=DEV), torch.zeros(L, device=DEV)
+    fused.layernorm_nobias_t2i_quant_sum_fuse(q, x, w, sh, sc, ssum, scale, 1e-6)
+    qi = q.to(torch.int32)
+    assert bool((qi.abs().amax(1) == 127).all())
+    np.testing.assert_allclose(ssum.cpu().numpy(), qi.sum(1).cpu().numpy().astype(np.float64) * scale.cpu().numpy().astype(np.float64), rtol=1e-6, atol=1e-6)
+    rows = np.unique(np.concatenate([np.random.default_rng(8).integers(0, L, 40), [0, L - 1]]))
+    oq, oscale, _ = kr.layernorm_t2i_quant_sum(x[rows].cpu().numpy(), w.cpu().numpy(), sh.cpu().numpy(), sc.cpu().numpy(), 1e-6, len(rows))
+    np.testing.assert_allclose(scale[rows].cpu().numpy(), oscale, rtol=1e-5)
+    d = np.abs(q[rows].cpu().numpy().astype(np.int32) - oq.astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3, (d.max(), (d != 0).mean())
+
+
+@pytest.mark.parametrize("cols,dtype", [(C, torch.float32), (F, torch.bfloat16)])
+def test_calibration_column_absmax_full_size_exact(cols, dtype):
+    """A8 at the size of one hook call of the headline run (W/get_calib_data_wanx.py:262-267): a maximum is order independent, so
+    the whole result is exact; the running buffer keeps what it already held."""
+    import viditq_extension.fused as fused
+
+    g = torch.Generator(device=DEV).manual_seed(cols + 1)
+    x = (torch.randn(L, cols, device=DEV, generator=g) * torch.exp(torch.randn(cols, device=DEV, generator=g))).to(dtype)
+    running = torch.full((cols,), 0.25, device=DEV)
+    running[5] = 1e9
+    fused.col_absmax_(running, x)
+    want = torch.maximum(x.float().abs().amax(0), torch.full((cols,), 0.25, device=DEV))
+    want[5] = 1e9
+    assert torch.equal(running, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_v_fake_quant_full_size_whole_output(dtype):
+    """attn.v at [32760, 12 x 128]: the per-(head, channel) DynamicQuantizer over all tokens, whole output bit for bit against the
+    oracle function."""
+    import viditq_extension.fused as fused
+    from oracle import wan_ref as wr
+
+    g = torch.Generator(device=DEV).manual_seed(33)
+    v = (torch.randn(L, C, device=DEV, generator=g) * torch.exp(torch.randn(C, device=DEV, generator=g))).to(dtype)
+    v[:, 3] = 0
+    # the oracle runs on the CPU: torch's fp32 division on the GPU is not the IEEE quotient (evaluated there, the same function
+    # differs from its CPU result on 1.8e6 of the 5e7 elements; tools/probes/vq_fullsize_diag.py), the kernel's is
+    ref = wr.v_fake_quant(v.float().cpu().view(L, H, 128), 8).reshape(L, C)
+    out, colmax = fused.fake_quant_cols_(v.clone(), 8)
+    assert torch.equal(colmax, v.float().abs().amax(0))
+    assert torch.equal(out.float().cpu(), ref.to(dtype).float()) and float(out[:, 3].abs().max()) == 0
+
+
+def test_int8_qk_attention_full_size_sampled_queries():
+    """attn.qk at the headline size: RMSNorm + RoPE + per-(token, head) int8 codes for q and k over the 21 x 30 x 52 grid (codes
+    against the oracle chain on sampled rows), then int8 Q.K^T attention over all 32760 keys against the fp32 definition on the
+    kernel's own codes (sampled queries)."""
+    from oracle import qdiff_ref as qr
+    from oracle import wan_ref as wr
+    from wan import ops
+
+    d, grid = 128, (21, 30, 52)
+    g = torch.Generator(device=DEV).manual_seed(88)
+    xq = (torch.randn(L, C, device=DEV, generator=g) * torch.exp(0.5 * torch.randn(C, device=DEV, generator=g))).to(torch.bfloat16)
+    xk = (torch.randn(L, C, device=DEV, generator=g) * torch.exp(0.5 * torch.randn(C, device=DEV, generator=g))).to(torch.bfloat16)
+    v = torch.randn(L, C, device=DEV, generator=g).to(torch.bfloat16)
+    w = torch.rand(C, device=DEV, generator=g) + 0.5
+    freqs = wr.rope_freqs(d)
+    table = ops.rope_table(freqs, grid, DEV)
+    q8 = ops.rmsnorm_rope_q8(xq, w, table, d, False)
+    k8 = ops.rmsnorm_rope_q8(xk, w, table, d, True)
+    rows = torch.from_numpy(np.unique(np.concatenate([np.random.default_rng(3).integers(0, L, 40), [0, 255, 256, L - 1]]))).to(DEV)
+    for x, c8 in ((xq, q8), (xk, k8)):
+        full = wr.rope_apply(wr.rms_norm(x.float(), w, 1e-6).view(L, H, d), grid, freqs.to(DEV))  # [L, H, d]
+        oq, oscale = qr.dynamic_quantize_sym(full[rows].reshape(-1, d).cpu().numpy())
+        scale = c8.scales[0, :, :L].t()[rows].reshape(-1).cpu().numpy()
+        np.testing.assert_allclose(scale, oscale.reshape(-1), rtol=2e-5)
+        dq = np.abs(c8.codes[rows].cpu().numpy().astype(np.int32).reshape(-1, d) - oq.astype(np.int32))
+        assert dq.max() <= 1 and (dq != 0).mean() < 5e-3, (dq.max(), (dq != 0).mean())
+    out = ops.attention_qk8(q8, k8, v, H)
+    assert bool(torch.isfinite(out.float()).all())
+    qf = q8.codes[rows].float().view(-1, H, d) * q8.scales[0, :, :L].t()[rows].unsqueeze(-1)
+    kf = k8.codes.float().view(L, H, d) * k8.scales[0, :, :L].t().unsqueeze(-1)
+    s = qf.transpose(0, 1) @ kf.permute(1, 2, 0) / d ** 0.5                       # [H, S, L]
+    ref = (torch.softmax(s, dim=-1) @ v.float().view(L, H, d).transpose(0, 1)).transpose(0, 1).reshape(len(rows), C)
+    got = out[rows].float()
+    assert float((got - ref).abs().max()) < 3e-2 and float((got - ref).norm() / ref.norm()) < 1e-2
