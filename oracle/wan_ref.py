@@ -210,6 +210,33 @@ class BlockRef:
         return x + y * e[5]
 
 
+    def rows(self, x, e0, grid, seq_len, context, freqs, rows):
+        """__call__(...)[rows] without computing the other rows' outputs: only the self-attention keys and values need every
+        token (LayerNorm, the per-token dynamic quantisers, the Linears, cross-attention and the FFN are all row-local), so a
+        headline-size block (L = 32760) is checked on a sample of rows in seconds.  FP attention only (the Wan wiring);
+        tests/test_oracle_golden.py checks it against __call__ at a small size."""
+        assert not (self.qk_bits or self.v_bits or self.attn_map or self.cross_qk_bits or self.cross_v_bits or self.cross_attn_map)
+        L, C = x.shape
+        n, d = self.n, C // self.n
+        rows = torch.as_tensor(rows, dtype=torch.long)
+        S = len(rows)
+        e = [t.reshape(1, C) for t in (self.mod + e0.float()).chunk(6, dim=1)]
+        h = layer_norm(x, self.eps) * (1 + e[1]) + e[0]
+        k = rope_apply(rms_norm(self.lin["self_attn.k"](h), self.norm_w["self_attn.norm_k"], self.eps).view(L, n, d), grid, freqs)
+        v = self.lin["self_attn.v"](h).view(L, n, d)
+        q_all = torch.zeros(L, n, d)
+        q_all[rows] = rms_norm(self.lin["self_attn.q"](h[rows]), self.norm_w["self_attn.norm_q"], self.eps).view(S, n, d)
+        q = rope_apply(q_all, grid, freqs)[rows]  # the rotation depends on the row's position in the grid
+        xr = x[rows] + self.lin["self_attn.o"](attention(q, k, v, seq_len).reshape(S, C)) * e[2]
+        h = layer_norm(xr, self.eps, *(self.norm3 or (None, None)))
+        q = rms_norm(self.lin["cross_attn.q"](h), self.norm_w["cross_attn.norm_q"], self.eps).view(S, n, d)
+        k = rms_norm(self.lin["cross_attn.k"](context), self.norm_w["cross_attn.norm_k"], self.eps).view(-1, n, d)
+        v = self.lin["cross_attn.v"](context).view(-1, n, d)
+        xr = xr + self.lin["cross_attn.o"](attention(q, k, v).reshape(S, C))
+        h = layer_norm(xr, self.eps) * (1 + e[4]) + e[3]
+        return xr + self.lin["ffn.2"](F.gelu(self.lin["ffn.0"](h), approximate="tanh")) * e[5]
+
+
 LINEARS = ("self_attn.q", "self_attn.k", "self_attn.v", "self_attn.o", "cross_attn.q", "cross_attn.k", "cross_attn.v",
            "cross_attn.o", "ffn.0", "ffn.2")
 

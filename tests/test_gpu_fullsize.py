@@ -455,3 +455,68 @@ def test_int8_qk_attention_full_size_sampled_queries():
     ref = (torch.softmax(s, dim=-1) @ v.float().view(L, H, d).transpose(0, 1)).transpose(0, 1).reshape(len(rows), C)
     got = out[rows].float()
     assert float((got - ref).abs().max()) < 3e-2 and float((got - ref).norm() / ref.norm()) < 1e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# One WHOLE kernel-mode block of the headline workload -- L = 32760 tokens over the 21 x 30 x 52 grid, C = 1536, 12 heads,
+# F = 8960, 512 context tokens, the configuration bench.py measures (quant_configs/w8a8_all_linears.yaml: every Linear W8A8,
+# ViDiT-Q scale + rotate on self_attn q / k / v) -- against the simulation-mode oracle on a sample of rows.  Everything in the
+# block but the self-attention keys and values is row-local, so the oracle computes k and v for all tokens and the rest for the
+# sampled rows only (oracle/wan_ref.py::BlockRef.rows, checked against the full block in tests/test_oracle_golden.py).
+def test_headline_block_full_size_sampled_rows_vs_simulation_oracle():
+    from oracle import qdiff_ref as qr
+    from oracle import wan_ref as wr
+    from qdiff import config as qcfg
+    from qdiff.base.quant_model import quant_layer_refactor_
+    from qdiff.utils import apply_func_to_submodules
+    from wan import calib, ops
+    from wan.modules.model import WanAttentionBlock
+    from wan.quant_wanx_hip import WanAttentionBlockWithHipKernel, _FpSrc
+
+    grid, lc = (21, 30, 52), 512
+    torch.manual_seed(7)
+    blk = WanAttentionBlock("t2v_cross_attn", C, F, H, cross_attn_norm=True)
+    for m in blk.modules():
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.xavier_uniform_(m.weight)
+            torch.nn.init.normal_(m.bias, std=0.05)
+    blk.norm3.weight.data.uniform_(0.5, 1.5)
+    blk.norm3.bias.data.normal_(std=0.1)
+    for nm in (blk.self_attn.norm_q, blk.self_attn.norm_k, blk.cross_attn.norm_q, blk.cross_attn.norm_k):
+        nm.weight.data.uniform_(0.5, 1.5)
+    sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(L, C, generator=g)
+    x[:, 9] *= 15.0  # an outlier channel
+    e0 = torch.randn(1, 6, C, generator=g) * 0.3
+    ctx = torch.randn(lc, C, generator=g)
+    freqs = wr.rope_freqs(C // H)
+    act_mask = torch.rand(C, generator=g) * 3 + 0.2
+
+    cfg = qcfg.create({"weight": {"n_bits": 8, "sym": False}, "act": {"n_bits": 8, "sym": True},
+                       "viditq": {"alpha": 0.5665, "layer_name_regex": r"self_attn\.(q|k|v)$"}, "remain_fp_regex": None})
+    blk = blk.to(DEV)
+    apply_func_to_submodules(blk, torch.nn.Linear, quant_layer_refactor_, name=None, parent_module=None, quant_config=cfg,
+                             full_name=None, remain_fp_regex=cfg.remain_fp_regex)
+    gen = torch.Generator().manual_seed(11)
+    vidit = {}
+    for name in ("q", "k", "v"):
+        lin = getattr(blk.self_attn, name)
+        assert type(lin).__name__ == "ViDiTQuantizedLinear"
+        calib.init_rotation_and_channel_mask_(lin, "x", {"x": act_mask[None]}, gen)
+        vidit["self_attn." + name] = (lin.channel_mask.cpu(), torch.from_numpy(qr.hadamard_from_signs(lin.rotation_signs.numpy())))
+    assert type(blk.self_attn.o).__name__ == "QuantizedLinear" and type(blk.ffn[2]).__name__ == "QuantizedLinear"
+
+    hb = WanAttentionBlockWithHipKernel.from_float(blk, None)
+    assert hb.self_attn.q.quantized and hb.self_attn.q.rot[0] == 12 and hb.self_attn.o.quantized and hb.ffn2.quantized
+    out = hb(x.to(DEV).clone(), e0.to(DEV), ops.rope_table(freqs, grid, DEV), L, _FpSrc(ctx.to(DEV), torch.bfloat16))
+    assert bool(torch.isfinite(out).all())
+
+    rows = np.unique(np.concatenate([np.random.default_rng(12).integers(0, L, 28), [0, 255, 256, L - 249, L - 1]]))
+    ref_q = wr.block_from_state(sd, H, quant=True, vidit=vidit).rows(x, e0, grid, L, ctx, freqs, rows)
+    ref_fp = wr.block_from_state(sd, H, quant=False).rows(x, e0, grid, L, ctx, freqs, rows)
+    got = out[torch.from_numpy(rows).to(DEV)].float().cpu()
+    err = float((got.double() - ref_q.double()).norm() / ref_q.double().norm())
+    noise = float((ref_q.double() - ref_fp.double()).norm() / ref_fp.double().norm())
+    print(f"headline block, {len(rows)} rows: rel err vs fake-quant oracle {err:.2e}; fake-quant vs fp {noise:.2e}")
+    assert err < 1e-2 and err < 0.5 * noise + 5e-3, (err, noise)  # the bars of tests/test_gpu_block.py's small-size block tests

@@ -278,3 +278,38 @@ def test_a2_dynamic_quantizer_asymmetric_branch_vs_reference(golden, bits):
         wdq = qr.static_fake_quant(g["w"], 8, False)[0]
         y = qr.dynamic_fake_quant_asym(g["x"], 8).astype(np.float64) @ wdq.astype(np.float64).T + g["b"]
         assert np.abs(y - g["y"]).max() < 2e-5 * np.abs(g["y"]).max()
+
+
+def test_block_oracle_on_sampled_rows_equals_the_full_block():
+    """BlockRef.rows (what the headline-size block test compares against) == BlockRef.__call__ on those rows: every step but the
+    self-attention keys / values is row-local.  ViDiT layers on q / k / v as in the headline configuration."""
+    import torch
+
+    from oracle import wan_ref as wr
+
+    dim, ffn, heads, grid, lc = 256, 512, 2, (3, 4, 5), 24
+    n_tok = grid[0] * grid[1] * grid[2]
+    g = torch.Generator().manual_seed(5)
+    sd = {}
+    for name in wr.LINEARS:
+        o, i = (ffn, dim) if name == "ffn.0" else (dim, ffn) if name == "ffn.2" else (dim, dim)
+        sd[name + ".weight"] = torch.randn(o, i, generator=g) / i ** 0.5
+        sd[name + ".bias"] = torch.randn(o, generator=g) * 0.05
+    for k in ("self_attn.norm_q", "self_attn.norm_k", "cross_attn.norm_q", "cross_attn.norm_k"):
+        sd[k + ".weight"] = torch.rand(dim, generator=g) + 0.5
+    sd["norm3.weight"], sd["norm3.bias"] = torch.rand(dim, generator=g) + 0.5, torch.randn(dim, generator=g) * 0.1
+    sd["modulation"] = torch.randn(1, 6, dim, generator=g) / dim ** 0.5
+    signs = (torch.randint(0, 2, (dim,), generator=g) * 2 - 1).double().numpy()
+    R = torch.from_numpy(qr.hadamard_from_signs(signs))
+    vidit = {n: (torch.rand(dim, generator=g) + 0.5, R) for n in ("self_attn.q", "self_attn.k", "self_attn.v")}
+    x = torch.randn(n_tok + 3, dim, generator=g)
+    x[n_tok:] = 0
+    e0 = torch.randn(1, 6, dim, generator=g) * 0.3
+    ctx = torch.randn(lc, dim, generator=g)
+    freqs = wr.rope_freqs(dim // heads)
+    for quant in (True, False):
+        blk = wr.block_from_state(sd, heads, quant=quant, vidit=vidit if quant else None)
+        full = blk(x, e0, grid, n_tok, ctx, freqs)
+        rows = [0, 7, 19, 33, n_tok - 1]
+        sub = blk.rows(x, e0, grid, n_tok, ctx, freqs, rows)
+        np.testing.assert_allclose(sub.numpy(), full[rows].numpy(), rtol=2e-5, atol=2e-5)
