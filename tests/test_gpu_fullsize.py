@@ -520,3 +520,58 @@ def test_headline_block_full_size_sampled_rows_vs_simulation_oracle():
     noise = float((ref_q.double() - ref_fp.double()).norm() / ref_fp.double().norm())
     print(f"headline block, {len(rows)} rows: rel err vs fake-quant oracle {err:.2e}; fake-quant vs fp {noise:.2e}")
     assert err < 1e-2 and err < 0.5 * noise + 5e-3, (err, noise)  # the bars of tests/test_gpu_block.py's small-size block tests
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The 8960-column ViDiT transform (rotate140_kernel: ffn.2's input under the reference's shipped config.yaml) and the fused
+# CFG + scheduler update, at the headline sizes.
+def test_rotate_8960_full_size_sampled_rows():
+    import viditq_extension.fused as fused
+    from oracle import qdiff_ref as qr
+    from qdiff.quarot import quarot_utils as qu
+
+    g = torch.Generator(device=DEV).manual_seed(140)
+    x = (torch.randn(L, F, device=DEV, generator=g) * torch.exp(0.7 * torch.randn(F, device=DEV, generator=g))).clamp_min(-0.17).to(torch.bfloat16)
+    x[5] = 0  # an all-zero token: the eps rule
+    pm = (torch.rand(F, device=DEV, generator=g) + 0.5) * (torch.randint(0, 2, (F,), device=DEV, generator=g) * 2 - 1).float()
+    rot = qu.kernel_rotation_params(F, DEV)
+    assert rot[0] == 140
+    scale, ssum = torch.zeros(L, device=DEV), torch.zeros(L, device=DEV)
+    q = fused.rotate_quant(x, pm, rot, ssum, scale)
+    qi = q.to(torch.int32)
+    live = torch.ones(L, dtype=torch.bool, device=DEV)
+    live[5] = False
+    assert bool((qi.abs().amax(1)[live] == 127).all()) and int(qi[5].abs().max()) == 0 and scale[5].item() == pytest.approx(1e-6)
+    np.testing.assert_allclose(ssum.cpu().numpy(), qi.sum(1).cpu().numpy().astype(np.float64) * scale.cpu().numpy().astype(np.float64), rtol=1e-6, atol=1e-6)
+    rows = np.unique(np.concatenate([np.random.default_rng(14).integers(0, L, 24), [0, 4, 5, 6, L - 1]]))
+    ref = qr.matmul_hadU(x[rows].double().cpu().numpy() * pm.double().cpu().numpy()).astype(np.float32)
+    oq, oscale = qr.dynamic_quantize_sym(ref)
+    np.testing.assert_allclose(scale[rows].cpu().numpy(), oscale, rtol=2e-6)
+    d = np.abs(q[rows].cpu().numpy().astype(np.int32) - oq)
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3, (d.max(), (d != 0).mean())
+
+
+@pytest.mark.parametrize("solver", ["unipc", "dpm++", "euler"])
+def test_fused_step_full_latent_equals_plain_scheduler(solver):
+    """CFG combine + scheduler update as one kernel on the headline latent [16, 21, 60, 104], 30 steps, against the plain
+    scheduler classes (pinned by the reference's own fm_solvers files in tests/test_schedulers_cpu.py)."""
+    from wan.utils.fm_solvers import FlowDPMSolverMultistepScheduler, FlowMatchScheduler
+    from wan.utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
+    from wan.utils.fused_step import FusedStep, _takes_timestep
+
+    mk = {"unipc": lambda: FlowUniPCMultistepScheduler(1000, shift=1.0), "dpm++": lambda: FlowDPMSolverMultistepScheduler(1000),
+          "euler": lambda: FlowMatchScheduler(1000)}[solver]
+    a, b = mk(), mk()
+    a.set_timesteps(30, device=DEV, shift=5.0)
+    b.set_timesteps(30, device=DEV, shift=5.0)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    x = torch.randn(16, 21, 60, 104, device=DEV, generator=g)
+    xa, xb = x.clone(), x.clone()
+    f = FusedStep(b, 5.0, like=x)
+    for t in a.timesteps:
+        c, u = torch.randn(x.shape, device=DEV, generator=g), torch.randn(x.shape, device=DEV, generator=g)
+        noise = u + 5.0 * (c - u)
+        xa = a.step(noise, t, xa) if _takes_timestep(a) else a.step(noise, xa)
+        xb = f.step(c, u, xb, t)
+        assert float((xa - xb).abs().max() / xa.abs().max()) < 2e-6
+    assert f.n_launch == 30
