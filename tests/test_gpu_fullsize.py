@@ -575,3 +575,46 @@ def test_fused_step_full_latent_equals_plain_scheduler(solver):
         xb = f.step(c, u, xb, t)
         assert float((xa - xb).abs().max() / xa.abs().max()) < 2e-6
     assert f.n_launch == 30
+
+
+def test_14b_block_full_sequence_sampled_rows_vs_simulation_oracle():
+    """One kernel-mode block with the 14B dimensions (C = 5120, 40 heads, F = 13824) on the WHOLE 1280x720x81f sequence
+    (75600 tokens over the 21 x 45 x 80 grid: 295 full 256-row tiles + 80 rows), every Linear W8A8 -- the single-GPU form of
+    BASELINE config 4 -- against the simulation oracle on sampled rows (plain fake-quant Linears: the fp64 rotation of 75600 x 5120
+    rows would take the host minutes; the ViDiT layers are covered at this width by tests/test_gpu_block.py and at L = 32760 above)."""
+    from oracle import wan_ref as wr
+    from wan import ops
+    from wan.modules.model import WanAttentionBlock
+    from wan.quant_wanx_hip import WanAttentionBlockWithHipKernel, _FpSrc
+
+    Lb, Cb, Fb, Hb, grid, lc = 75600, 5120, 13824, 40, (21, 45, 80), 512
+    assert grid[0] * grid[1] * grid[2] == Lb
+    torch.manual_seed(14)
+    blk = WanAttentionBlock("t2v_cross_attn", Cb, Fb, Hb, cross_attn_norm=True)
+    for m in blk.modules():
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.xavier_uniform_(m.weight)
+            torch.nn.init.normal_(m.bias, std=0.05)
+    blk.norm3.weight.data.uniform_(0.5, 1.5)
+    blk.norm3.bias.data.normal_(std=0.1)
+    for nm in (blk.self_attn.norm_q, blk.self_attn.norm_k, blk.cross_attn.norm_q, blk.cross_attn.norm_k):
+        nm.weight.data.uniform_(0.5, 1.5)
+    sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    g = torch.Generator().manual_seed(15)
+    x = torch.randn(Lb, Cb, generator=g)
+    x[:, 9] *= 15.0
+    e0 = torch.randn(1, 6, Cb, generator=g) * 0.3
+    ctx = torch.randn(lc, Cb, generator=g)
+    freqs = wr.rope_freqs(Cb // Hb)
+
+    hb = WanAttentionBlockWithHipKernel.from_float(blk.to(DEV))
+    out = hb(x.to(DEV).clone(), e0.to(DEV), ops.rope_table(freqs, grid, DEV), Lb, _FpSrc(ctx.to(DEV), torch.bfloat16))
+    assert bool(torch.isfinite(out).all())
+    rows = np.unique(np.concatenate([np.random.default_rng(16).integers(0, Lb, 16), [0, 255, 256, Lb - 81, Lb - 1]]))
+    ref_q = wr.block_from_state(sd, Hb, quant=True).rows(x, e0, grid, Lb, ctx, freqs, rows)
+    ref_fp = wr.block_from_state(sd, Hb, quant=False).rows(x, e0, grid, Lb, ctx, freqs, rows)
+    got = out[torch.from_numpy(rows).to(DEV)].float().cpu()
+    err = float((got.double() - ref_q.double()).norm() / ref_q.double().norm())
+    noise = float((ref_q.double() - ref_fp.double()).norm() / ref_fp.double().norm())
+    print(f"14B block, 75600 tokens, {len(rows)} rows: rel err vs fake-quant oracle {err:.2e}; fake-quant vs fp {noise:.2e}")
+    assert err < 1e-2 and err < 0.5 * noise + 5e-3, (err, noise)
