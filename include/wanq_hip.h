@@ -96,6 +96,14 @@ int wanq_gemm_w8a8(const int8_t* a, const int8_t* w, void* out, int out_dtype, c
                    const void* zp, int zp_dtype, const float* gate, const void* residual, int epi_flags,
                    int64_t M, int N, int K, void* stream);
 
+/* Diagnostic: which int8 GEMM kernel wanq_gemm_w8a8 / wanq_gemm_w4a8 launch.  0 = automatic (default: the ping-pong persistent
+ * kernel where a problem is eligible, else the persistent kernel, else the 128 x 128 kernel), 1 = always the 128 x 128
+ * kernel, 2 = never the ping-pong kernel.  Process-wide; returns the previous setting (or -1 for a bad value, nothing changed).
+ * Accumulators are bit-identical across the three kernels and so are the outputs of the two persistent ones; the 128 x 128
+ * kernel sums the epilogue terms in another order (one unit of the output type; tests/test_gpu_gemm.py).  The environment variables
+ * WANQ_GEMM_V1=1 / WANQ_GEMM_PP=0 set the same thing at start-up for whole-step A/B runs.  No reference counterpart. */
+int wanq_gemm_select_kernel(int which);
+
 /* ------------------------------------------------------------------------------------------------
  * PTQ calibration reduction: running per-channel absmax over tokens,
  *   colmax[c] = max(colmax[c], max_r |x[r,c]|)        (colmax fp32[cols], caller zero-initialises)

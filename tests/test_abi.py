@@ -64,7 +64,7 @@ def test_round2_entry_points_refuse_bad_arguments(lib):
     i64 = ctypes.c_int64
     buf = ctypes.create_string_buffer(256)
     p = ctypes.cast(buf, ctypes.c_void_p)
-    assert lib.wanq_abi_version() == 3
+    assert lib.wanq_abi_version() == 4
     # W4A8: K must hold whole 32-code groups
     rc = lib.wanq_gemm_w4a8(p, p, p, 0, p, None, 0, p, None, 0, None, 0, None, None, 0, i64(8), 16, 48, None)
     assert rc == 2 and b"K=48" in lib.wanq_last_error()
@@ -125,3 +125,12 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(d, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_gemm_kernel_selection_is_a_host_side_setting(lib):
+    """wanq_gemm_select_kernel (ABI 4) only records which kernel later GEMM calls launch: no GPU needed, bad values refused."""
+    prev = lib.wanq_gemm_select_kernel(2)
+    assert prev in (0, 1, 2)
+    assert lib.wanq_gemm_select_kernel(1) == 2
+    assert lib.wanq_gemm_select_kernel(7) == -1 and lib.wanq_gemm_select_kernel(-1) == -1
+    assert lib.wanq_gemm_select_kernel(prev) == 1

@@ -231,3 +231,81 @@ def test_w4a8_epilogue_matches_w8a8_on_unpacked_codes():
         # (the +8 bias makes acc_u larger than acc_q and cancels in the zero-point term: ~1e-6 of the largest term in fp32)
         tol = 1e-4 if kw["out_dtype"] == torch.float32 else 1e-2
         assert torch.allclose(y4.float(), y8.float(), rtol=tol, atol=tol * float(y8.float().abs().max())), (y4.float() - y8.float()).abs().max()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The ping-pong persistent kernel (csrc/gemm_w8a8_pp.hip) against the other two kernels in ONE process
+# (wanq_gemm_select_kernel): same accumulators; the two persistent kernels share the epilogue expression -> bit-identical.
+def _select(which):
+    from viditq_extension import _C
+
+    prev = _C.lib.wanq_gemm_select_kernel(which)
+    assert prev >= 0
+    return prev
+
+
+@pytest.fixture
+def kernel_select():
+    yield _select
+    _select(0)
+
+
+PP_SHAPES = [  # (M, N, K): two / three / odd numbers of K-tiles, ragged M and N, several tiles per workgroup, one workgroup only
+    (512, 256, 256), (777, 264, 384), (2100, 520, 640), (4680, 1536, 1536), (33000, 1536, 256), (9450, 1024, 1152), (600, 4096, 512)]
+
+
+@pytest.mark.parametrize("M,N,K", PP_SHAPES)
+def test_pingpong_kernel_bit_equal_to_the_other_kernels(kernel_select, M, N, K):
+    g = torch.Generator(device=DEV).manual_seed(M * 3 + N + K)
+    a = torch.randint(-128, 128, (M, K), dtype=torch.int8, device=DEV, generator=g)
+    w = torch.randint(-128, 128, (N, K), dtype=torch.int8, device=DEV, generator=g)
+    sa = torch.rand(M, device=DEV, generator=g) * 0.01 + 1e-3
+    asum = a.float().sum(1) * sa
+    sw = torch.rand(N, device=DEV, generator=g) * 0.01 + 1e-3
+    zp = torch.randn(N, device=DEV, generator=g).round() * 3
+    bias = torch.randn(N, device=DEV, generator=g)
+    gate = torch.randn(N, device=DEV, generator=g)
+    res = torch.randn(M, N, device=DEV, generator=g)
+
+    def run_all():
+        outs = [qgemm().w8a8_o32(a, w)]
+        for od in (torch.bfloat16, torch.float16, torch.float32):
+            outs.append(qgemm().w8a8_linear(a, w, sa, sw, bias, asum, zp, out_dtype=od))
+            outs.append(qgemm().w8a8_linear(a, w, sa, sw, None, None, None, out_dtype=od))  # symmetric weights, no bias
+        outs.append(qgemm().w8a8_linear(a, w, sa, sw, bias, asum, zp, out_dtype=torch.bfloat16, gelu=True))
+        outs.append(qgemm().w8a8_linear(a, w, sa, sw, bias, asum, zp, out_dtype=torch.float32, gate=gate, residual=res))
+        # fp16 vectors + int16 zero points (the reference's buffer dtypes): the kernel's non-prefetched scale path
+        outs.append(qgemm().w8a8_linear(a, w, sa.half(), sw.half(), bias.half(), asum.half(), zp.to(torch.int16), out_dtype=torch.float16))
+        buf = res.clone()  # in place, as the block calls it
+        qgemm().w8a8_linear(a, w, sa, sw, bias, asum, zp, out_dtype=torch.float32, gate=gate, residual=buf, out=buf)
+        outs.append(buf)
+        return outs
+
+    kernel_select(0)
+    y_pp = run_all()
+    kernel_select(2)
+    y_v2 = run_all()
+    kernel_select(1)
+    y_v1 = run_all()
+    assert np.array_equal(y_pp[0].cpu().numpy(), kr.w8a8_o32(a.cpu().numpy(), w.cpu().numpy()))
+    assert torch.equal(y_pp[0], y_v1[0])
+    for i, (p_, v2, v1) in enumerate(zip(y_pp, y_v2, y_v1)):
+        assert torch.equal(p_, v2), f"output {i}: ping-pong != persistent"
+        # the 128 x 128 kernel sums the epilogue's three terms in another order: equal to one unit of the output type
+        eps = {torch.int32: 0, torch.float16: 2 ** -10, torch.bfloat16: 2 ** -7, torch.float32: 4e-6}[p_.dtype]
+        d = (p_.double() - v1.double()).abs()
+        assert (d <= v1.double().abs() * eps + 1e-4).all(), f"output {i}: ping-pong vs 128x128 kernel"
+
+
+def test_pingpong_kernel_repeated_launches_are_deterministic(kernel_select):
+    """Race screen of the LDS ring: 20 launches of a several-tiles-per-workgroup problem, every output equal to the first."""
+    M, N, K = 32760, 1536, 1536
+    g = torch.Generator(device=DEV).manual_seed(11)
+    a = torch.randint(-128, 128, (M, K), dtype=torch.int8, device=DEV, generator=g)
+    w = torch.randint(-128, 128, (N, K), dtype=torch.int8, device=DEV, generator=g)
+    kernel_select(0)
+    first = qgemm().w8a8_o32(a, w)
+    for _ in range(20):
+        assert torch.equal(qgemm().w8a8_o32(a, w), first)
+    kernel_select(2)
+    assert torch.equal(qgemm().w8a8_o32(a, w), first)

@@ -13,7 +13,7 @@
 // them (one barrier per K tile).  LDS rows are 128 B with the 16-B chunk index XORed by (row>>1)&7:
 // ds_read_b128 fragment reads and ds_write_b128 staging writes are both bank-conflict free.
 // Workgroup ids are remapped so that each XCD's L2 sees a compact (8 m-tiles x n) panel.
-#include "wanq_common.h"
+#include "gemm_params.h"
 #include <stdlib.h>
 
 namespace wanq {
@@ -21,30 +21,18 @@ namespace wanq {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-struct GemmParams {
-  const int8_t* a;
-  const int8_t* w;
-  void* out;
-  const void* sa;
-  const void* asum;
-  const void* sw;
-  const void* bias;
-  const void* zp;
-  const float* gate;
-  const void* residual;
-  int tok_dtype, ch_dtype, zp_dtype, epi;
-  int M, N, K;
-  int mt, nt;
-  int group_m;  // v2: m-tiles per L2 panel
-};
-
 template <int OUT>
 __device__ __forceinline__ uint2 pack16x4(const float (&y)[4]) {
   uint2 v;
   if (OUT == WANQ_F16) {
+    // the fp32 value first, then its cast (the reference's order, w8a8_gemm_cuda.cu:416-442): without the opaque copies hipcc may
+    // contract the last fma and the cast into v_fma_mixlo_f16 -- one rounding instead of two, a different half in rare cases, and
+    // which of the two a kernel gets depends on the code around it
+    float z[4] = {y[0], y[1], y[2], y[3]};
+    asm volatile("" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]));
     __half2* h = reinterpret_cast<__half2*>(&v);
-    h[0] = __floats2half2_rn(y[0], y[1]);
-    h[1] = __floats2half2_rn(y[2], y[3]);
+    h[0] = __floats2half2_rn(z[0], z[1]);
+    h[1] = __floats2half2_rn(z[2], z[3]);
   } else {
     uint16_t b[4];
 #pragma unroll
@@ -60,7 +48,12 @@ __device__ __forceinline__ uint2 pack16x4(const float (&y)[4]) {
 constexpr int BM = 128, BN = 128, BK = 128;
 constexpr int STAGE_BYTES = (BM + BN) * BK;  // 32 KiB
 constexpr int GROUP_M = 4;  // m-tiles per L2 panel (sweep 2..32 on cfg-B: 4 best, 8 within 1-3 %; WANQ_GEMM_GROUP_M overrides)
-static bool g_force_v1 = false;  // test hook: WANQ_GEMM_V1=1 in the environment
+// kernel selection (wanq_gemm_select_kernel; environment at start-up: WANQ_GEMM_V1=1 -> 1, WANQ_GEMM_PP=0 -> 2)
+static int g_kernel_sel = [] {
+  const char* v1 = getenv("WANQ_GEMM_V1");
+  const char* pp = getenv("WANQ_GEMM_PP");
+  return (v1 && v1[0] == '1') ? 1 : (pp && pp[0] == '0') ? 2 : 0;
+}();
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -795,7 +788,7 @@ static int launch_gemm(GemmParams p, hipStream_t st) {
     return true;
   }();
   (void)attr_set;
-  if (p.M >= 512 && p.K % B2K == 0 && !g_force_v1 && (int64_t)p.M * p.K < (1ll << 32) && (int64_t)p.N * p.K < (1ll << 32)) {
+  if (p.M >= 512 && p.K % B2K == 0 && g_kernel_sel != 1 && (int64_t)p.M * p.K < (1ll << 32) && (int64_t)p.N * p.K < (1ll << 32)) {
     p.mt = (p.M + B2M - 1) / B2M;
     p.nt = (p.N + B2N - 1) / B2N;
     const int tiles = p.mt * p.nt;
@@ -837,10 +830,6 @@ static int gemm_entry(bool w4, const int8_t* a, const void* w, void* out, int ou
   }
   WANQ_REQUIRE((epi_flags & ~(WANQ_EPI_GELU | WANQ_EPI_GATE_RES)) == 0, WANQ_E_ARG, "%s: unknown epilogue flag", what);
   if (M == 0) return WANQ_OK;
-  {
-    static const bool v1 = [] { const char* e = getenv("WANQ_GEMM_V1"); return e && e[0] == '1'; }();
-    g_force_v1 = v1;
-  }
   static const int group_m = [] { const char* e = getenv("WANQ_GEMM_GROUP_M"); const int v = e ? atoi(e) : 0; return v > 0 ? v : GROUP_M; }();
   GemmParams p{};
   p.a = a; p.w = static_cast<const int8_t*>(w); p.out = out; p.sa = sa; p.asum = asum; p.sw = sw; p.bias = bias; p.zp = zp; p.gate = gate;
@@ -850,6 +839,7 @@ static int gemm_entry(bool w4, const int8_t* a, const void* w, void* out, int ou
   p.nt = (N + BN - 1) / BN;
   WANQ_REQUIRE((int64_t)p.mt * p.nt < (1ll << 31), WANQ_E_SHAPE, "%s: too many tiles", what);
   hipStream_t st = (hipStream_t)stream;
+  if (g_kernel_sel == 0 && gemm_pp_eligible(p, out_dtype, w4)) return launch_gemm_pp(p, out_dtype, st);  // ping-pong persistent kernel
   if (w4) {
     switch (out_dtype) {
       case WANQ_F16: return launch_gemm<WANQ_F16, true>(p, st);
@@ -876,6 +866,13 @@ extern "C" int wanq_gemm_w8a8(const int8_t* a, const int8_t* w, void* out, int o
                               int64_t M, int N, int K, void* stream) {
   return gemm_entry(false, a, w, out, out_dtype, sa, asum, tok_dtype, sw, bias, ch_dtype, zp, zp_dtype, gate, residual, epi_flags,
                     M, N, K, stream);
+}
+
+extern "C" int wanq_gemm_select_kernel(int which) {
+  if (which < 0 || which > 2) return -1;
+  const int prev = g_kernel_sel;
+  g_kernel_sel = which;
+  return prev;
 }
 
 extern "C" int wanq_gemm_w4a8(const int8_t* a, const uint8_t* w_packed, void* out, int out_dtype, const void* sa,

@@ -18,11 +18,15 @@ if not os.path.exists(LIB_PATH):
         f"`python wan2.1-quantization_amd/build.py` (hipcc --offload-arch=gfx950). "
         "There is no CPU or PyTorch fallback for the quantized hot path.")
 
+if os.environ.get("WANQ_LIB"):
+    import warnings
+
+    warnings.warn(f"WANQ_LIB overrides the hot-path library: loading {LIB_PATH} (A/B and diagnostic builds only)", RuntimeWarning)
 lib = ctypes.CDLL(LIB_PATH)
 
 F16, BF16, F32, I32, I16 = 0, 1, 2, 3, 4
 EPI_GELU, EPI_GATE_RES = 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
@@ -33,6 +37,7 @@ PROTOTYPES = {
     "wanq_gate_residual": [_vp, _i, _vp, _i, _i64, _vp, _i, _vp, _i, _i64, _i, _i64, _vp],
     "wanq_gemm_w8a8": [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i64, _i, _i, _vp],
     "wanq_gemm_w4a8": [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i64, _i, _i, _vp],
+    "wanq_gemm_select_kernel": [_i],
     "wanq_lincomb": [_i, _i, _vp, _vp, _vp, _i64, _vp],
     "wanq_col_absmax": [_vp, _i, _vp, _i64, _i, _vp],
     "wanq_row_minmax": [_vp, _i, _vp, _vp, _vp, _i64, _i, _vp],
