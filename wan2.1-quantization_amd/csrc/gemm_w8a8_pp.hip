@@ -59,6 +59,9 @@ constexpr int PBUF = (PM + PN) * PK;  // one K-tile buffer: 64 KiB
 constexpr int PXB = PM * PK;          // offset of the W rows inside a buffer
 constexpr int PTURN = 2 * PBUF;       // eight 4-KiB turn buffers behind the ring
 constexpr int PLDS = PTURN + 8 * 4096;  // 160 KiB
+#ifndef WANQ_PP_BURST
+#define WANQ_PP_BURST 32  // MFMAs per burst: 32 (two phases per K-tile, the shipped schedule) or 16 (four phases, the first form)
+#endif
 
 template <int OFF>
 __device__ __forceinline__ void dsr(v4i& d, uint32_t addr) {
@@ -182,16 +185,15 @@ __device__ __forceinline__ void prefetch_scales(const GemmParams& p, char* tb, i
   t0 = t0 < p.M ? t0 : p.M - 1;
   t1 = t1 < p.M ? t1 : p.M - 1;
   n = n < p.N ? n : p.N - 1;
+  // always EIGHT instructions (absent vectors re-request sW / sA into their unused slots): the schedule's vmcnt counts rely on it
   PP_SC_DMA(p.sa, t0, 0);
   PP_SC_DMA(p.sa, t1, 256);
-  if (p.zp) {
-    PP_SC_DMA(p.asum, t0, 512);
-    PP_SC_DMA(p.asum, t1, 768);
-    PP_SC_DMA(p.zp, n, 1280);
-  }
+  PP_SC_DMA(p.zp ? p.asum : p.sa, t0, 512);
+  PP_SC_DMA(p.zp ? p.asum : p.sa, t1, 768);
   PP_SC_DMA(p.sw, n, 1024);
-  if (p.bias) PP_SC_DMA(p.bias, n, 1536);
-  if (has_res) PP_SC_DMA(p.gate, n, 1792);
+  PP_SC_DMA(p.zp ? p.zp : p.sw, n, 1280);
+  PP_SC_DMA(p.bias ? p.bias : p.sw, n, 1536);
+  PP_SC_DMA(has_res ? static_cast<const void*>(p.gate) : p.sw, n, 1792);
 #undef PP_SC_DMA
 }
 template <int OFF>
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_pp_kernel(const GemmParams p
   const int nk = K / PK;
   const int ntiles = p.mt * p.nt;
   constexpr bool has_res = RES;
-  const bool fast_scales = scales_all_f32(p);
+  const bool fast_scales = scales_all_f32(p) && p.K >= 4 * PK;  // (>= 4 K-tiles: the prefetch sits two K-tiles in front of the epilogue)
   const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
 
   // tile id -> (m0, n0): XCD-contiguous ids (bijective remap; gridDim.x % 8 == 0), then groups of group_m m-tiles (v2's walk)
@@ -491,10 +493,17 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_pp_kernel(const GemmParams p
   set_sources(m0, n0, lane);
   bool pp_prologue = true;
   (void)pp_prologue;
+#if WANQ_PP_BURST == 32
+  // prologue = what the schedule would have issued in front of the first load phase, in its order: W(0), X(0), W(1)
+  PP_ISSUE_WA(); PP_ISSUE_WB(); PP_ISSUE_XA(); PP_ISSUE_XB_ADVANCE();
+  PP_ISSUE_WA(); PP_ISSUE_WB();
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#else
   // prologue = the seven chunk issues the schedule would have made in front of the first load phase, in its order
   PP_ISSUE_XA(); PP_ISSUE_WA(); PP_ISSUE_WB(); PP_ISSUE_XB_ADVANCE();
   PP_ISSUE_XA(); PP_ISSUE_WA(); PP_ISSUE_WB();
   asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+#endif
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   pp_prologue = false;
@@ -547,6 +556,23 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_pp_kernel(const GemmParams p
               __builtin_amdgcn_mfma_i32_16x16x64_i8(WF[ks_][ii_], xf[ks_][jj_], acc[(I0) + ii_][(J0) + jj_], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                                 \
   } while (0)
+  // the 32-MFMA form: all four channel blocks (W halves a and b) x the four token blocks J0 .. J0+3; the reads were waited for in
+  // front of the barrier
+#define PP_BURST32(J0)                                                                                             \
+  do {                                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    __builtin_amdgcn_s_setprio(1);                                                                                 \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                                          \
+      _Pragma("unroll") for (int ii_ = 0; ii_ < 2; ++ii_)                                                          \
+        _Pragma("unroll") for (int jj_ = 0; jj_ < 4; ++jj_)                                                        \
+          acc[ii_][(J0) + jj_] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wfa[ks_][ii_], xf[ks_][jj_], acc[ii_][(J0) + jj_], 0, 0, 0); \
+      _Pragma("unroll") for (int ii_ = 0; ii_ < 2; ++ii_)                                                          \
+        _Pragma("unroll") for (int jj_ = 0; jj_ < 4; ++jj_)                                                        \
+          acc[2 + ii_][(J0) + jj_] =                                                                               \
+              __builtin_amdgcn_mfma_i32_16x16x64_i8(wfb[ks_][ii_], xf[ks_][jj_], acc[2 + ii_][(J0) + jj_], 0, 0, 0); \
+    }                                                                                                              \
+    __builtin_amdgcn_s_setprio(0);                                                                                 \
+  } while (0)
 #define PP_READ_X(S)                                                                   \
   do {                                                                                 \
     dsr<(S) * 8192 + 0 * 2048>(xf[0][0], xa0); dsr<(S) * 8192 + 1 * 2048>(xf[0][1], xa0); \
@@ -578,6 +604,56 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_pp_kernel(const GemmParams p
       const bool hold = has_res && kt == nk - 1;  // residual epilogue ahead: the next tile's second K-tile is requested behind it
       const uint32_t xa0 = xrd[0] + bC, xa1 = xrd[1] + bC, wa0 = wrd[0] + bC, wa1 = wrd[1] + bC;
       v4i xf[2][4], wfa[2][2], wfb[2][2];
+#if WANQ_PP_BURST == 32
+      // ---- two phases per K-tile, 32-MFMA bursts (a 16-MFMA burst paid ~90 cycles of barrier / refill per 256: 2775 cycles per
+      // K-tile; profiles/r04_b_gemm_pingpong_clock.txt).  Slots relative to G0's first burst of K-tile t, G0 bursts in even slots:
+      //   slot -1 G0 LA: reads X0a, Wa, Wb (16)   issues X0a, X0b (t+1)        slot 0 G1 LA: X1a, Wa, Wb     issues X1a, X1b (t+1)
+      //   slot  1 G0 LB: reads X0b (8)            issues W rows of G0 (t+2)    slot 2 G1 LB: X1b             issues W rows of G1 (t+2)
+      // Bursts QA = Xa x (Wa, Wb), QB = Xb x (Wb, Wa).  Per wave the vector-memory queue is ... W(t+1) | X(t+1) | W(t+2) | X(t+2) ...
+      // (four pieces each): the wait at the END OF A BURST leaves the youngest group in flight and retires the one before it --
+      // W(t+1) behind QA(t), X(t+1) behind QB(t) -- 3.5 slots after its issue and one barrier before its first reader.  W is
+      // re-filled ONE slot after its last reader (G1's LA): load phases therefore finish their reads (lgkmcnt(0)) in front of
+      // their barrier, not behind it.
+      const bool sc_now = OUT != WANQ_I32 && fast_scales && kt == nk - 2;
+      // phase A
+      PP_READ_X(0);
+      PP_READ_W(wfa, 0);
+      PP_READ_W(wfb, 1);
+      PP_ISSUE_XA();
+      PP_ISSUE_XB_ADVANCE();
+      if (sc_now) {
+        int lane_s = lane;  // opaque: computed from `lane`, the eight addresses are tile-invariant and hipcc carries them (16 registers)
+        asm volatile("" : "+v"(lane_s));  // through the whole K loop, spilling other values
+        prefetch_scales(p, smem + PTURN + wave * 4096, n0 + c * 64, m0 + g * 128, lane_s, has_res);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PP_BAR();
+      PP_BURST32(0);
+      if (vm_left > 0) {  // first burst behind an epilogue: its stores (16 / 32 of a full tile) are younger than W(t+1)
+        vm_left = 0;
+        if (vm_mode == 1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else if (vm_mode == 2) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else if (sc_now) {
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // X(t+1) and the eight scale pieces stay in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      }
+      PP_BAR();
+      // phase B
+      PP_READ_X(1);
+      if (!hold) {
+        PP_ISSUE_WA();
+        PP_ISSUE_WB();
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PP_BAR();
+      PP_BURST32(4);
+      if (hold) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no W(t+2) was issued: X(t+1) is the youngest
+      else if (sc_now) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      PP_BAR();
+#else
       // phase 1
       PP_READ_X(0);
       PP_READ_W(wfa, 0);
@@ -619,6 +695,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_pp_kernel(const GemmParams p
       PP_BAR();
       PP_BURST(wfa, 0, 4);
       PP_BAR();
+#endif
       bC ^= PBUF;
     }
 #ifdef WANQ_PP_CLOCK
@@ -700,9 +777,14 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_pp_kernel(const GemmParams p
       // every wave is out of its residual ring before the held-back pieces (next tile, second K-tile) land in it
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       PP_BAR();
+#if WANQ_PP_BURST == 32
+      PP_ISSUE_WA(); PP_ISSUE_WB();  // W(1) of the next tile; its first burst's wait (vmcnt(4): X(1) only) retires it and the last stores
+      vm_left = 0;
+#else
       PP_ISSUE_XA(); PP_ISSUE_WA(); PP_ISSUE_WB();
       vm_mode = 3;
       vm_left = 3;
+#endif
     } else if (full_tile) {
       vm_mode = stores_mode;
       vm_left = 5;
@@ -722,6 +804,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_pp_kernel(const GemmParams p
 #undef PP_WAITVM
 #undef PP_BAR
 #undef PP_BURST
+#undef PP_BURST32
 #undef PP_READ_X
 #undef PP_READ_W
 }
