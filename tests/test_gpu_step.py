@@ -117,3 +117,54 @@ def test_graph_replay_of_the_dit_passes_is_bit_equal_to_eager():
         torch.cuda.synchronize()
         for e, o in zip(eager, outs):
             assert torch.equal(e, o)
+
+
+def test_graph_replay_survives_cache_eviction_and_sees_context_updates():
+    """The captured passes hold their own cross_attn.k / .v launches (the per-context cache is off during capture): a replay is
+    still right after more other contexts ran eagerly than the cache keeps, after the blocks' cache was dropped, and after an
+    in-place update of the graph's static context buffer."""
+    from qdiff import config as qcfg
+    from wan.configs import seq_len_for
+    from wan.graph import GraphedPasses
+    from wan.modules.model import WanModel
+    from wan.quant_wanx import QuantWanModel
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    quant_config = qcfg.load(os.path.join(root, "wan2.1-quantization_amd", "quant_configs", "w8a8_plain.yaml"))
+    torch.manual_seed(0)
+    with torch.device(DEV):
+        fp = WanModel(dim=512, ffn_dim=1024, num_heads=4, num_layers=2, text_dim=64, freq_dim=64).eval()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    torch.nn.init.xavier_uniform_(fp.head.head.weight, generator=g)
+    model = QuantWanModel.from_float(fp, quant_config)
+    model.quant_layer_refactor()
+    model.set_init_done()
+    model.hardware_forward_refactor()
+    shape = (16, 3, 20, 18)
+    seq_len = seq_len_for(shape)
+    ctx = [torch.randn(24, 64, device=DEV, generator=g) * 0.1 for _ in range(2)]
+    lat = torch.randn(shape, device=DEV, generator=g)
+    t = torch.tensor([700], device=DEV)
+    gp = GraphedPasses(model, lat, ctx, seq_len)
+    assert getattr(model, "context_cache", True)  # the capture restored the setting
+    want = [model([lat], t, [c], seq_len)[0].clone() for c in ctx]
+    # six other contexts through the eager path (the cache keeps four), with large temporaries in between
+    for i in range(6):
+        other = torch.randn(24, 64, device=DEV, generator=g)
+        model([lat], t, [other], seq_len)
+        del other
+        junk = torch.randn(1 << 22, device=DEV)
+        del junk
+    model.__dict__.pop("_ctx_cache", None)
+    torch.cuda.empty_cache()
+    outs = gp(lat, t)
+    torch.cuda.synchronize()
+    for w_, o in zip(want, outs):
+        assert torch.equal(w_, o)
+    # in-place update of the graph's own context buffer
+    new_ctx = torch.randn(24, 64, device=DEV, generator=g) * 0.1
+    gp.ctx[0].copy_(new_ctx)
+    outs = gp(lat, t)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], model([lat], t, [new_ctx], seq_len)[0])
+    assert torch.equal(outs[1], want[1])

@@ -21,7 +21,7 @@ vp, i, i64, f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 arr = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
 for k, (name, flags) in enumerate(variants):
     lib = os.path.join(out, f"libwanq_rot{k}.so")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-shared", *flags, "-o", lib, *srcs])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-shared", "-DWANQ_ALLOW_ABLATIONS", *flags, "-o", lib, *srcs])
     Lb = ctypes.CDLL(lib)
     fn = Lb.wanq_layernorm_rotate_quant_rows_multi
     fn.argtypes = [vp, i, vp, vp, vp, i, i64, i64, f, i, vp, i, vp, vp, vp, i, i64, i, vp]

@@ -676,6 +676,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef WANQ_ABL_NOEXP
 #define WANQ_ABL_NOEXP 0
 #endif
+#if (WANQ_ABL_NODMA || WANQ_ABL_NOMAX || WANQ_ABL_NOEXP) && !defined(WANQ_ALLOW_ABLATIONS)
+#error "WANQ_ABL_* build deliberately wrong kernels (timing ablations): add -DWANQ_ALLOW_ABLATIONS, never in build.py's library"
+#endif
 
 template <bool SPLIT, bool QK8>
 __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) {

@@ -163,7 +163,17 @@ __global__ __launch_bounds__(512, PASS == 2 ? 2 : 4) void attn_map_kernel(const 
 
   // S^T blocks of tile j (stage st): sacc[kb][nq][e] = score of query 16 nq + n16 against key 64 j + 16 kb + 4 pg + e, in the
   // log2 domain (bf16 form) or as dot * delta_k (int8 form: times c2[nq] gives the log2-domain score); keys >= Lk: -inf
-  auto s_tile = [&](int j, int st, mf32x4 (&sacc)[4][2]) {
+  // (int8 form) the four key-scale vectors of tile j, loaded IN FRONT OF the tile-(j+2) LDS-DMA of the same iteration: vmcnt retires
+  // in order, so a wait for loads issued behind that DMA would wait for the DMA too and the two-tiles-ahead ring would drain in
+  // every tile (pass 2 orders its delta loads the same way)
+  auto load_sk = [&](int j, mf32x4 (&skv)[4]) {
+    if (QK8) {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)  // (the planes are padded to whole tiles: the host checks the stride)
+        skv[kb] = *reinterpret_cast<const mf32x4*>(p.k_scale + (int64_t)head * p.ks_stride + j * AM_KB + 16 * kb + 4 * pg);
+    }
+  };
+  auto s_tile = [&](int j, int st, mf32x4 (&sacc)[4][2], const mf32x4 (&skv)[4]) {
     const char* sK = smem + st * AM_STAGE;
     if (!QK8) {
 #pragma unroll
@@ -187,8 +197,7 @@ __global__ __launch_bounds__(512, PASS == 2 ? 2 : 4) void attn_map_kernel(const 
           ia0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf8, qf8[0][QK8 ? s : 0], ia0, 0, 0, 0);
           ia1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(kf8, qf8[QK8 ? 1 : 0][QK8 ? s : 0], ia1, 0, 0, 0);
         }
-        // the lane's four keys of this block: their scales (the planes are padded to whole tiles: the host checks the stride)
-        const mf32x4 sk = *reinterpret_cast<const mf32x4*>(p.k_scale + (int64_t)head * p.ks_stride + j * AM_KB + 16 * kb + 4 * pg);
+        const mf32x4 sk = skv[kb];  // the lane's four keys of this block: their scales
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           sacc[kb][0][e] = (float)ia0[e] * sk[e];
@@ -218,9 +227,11 @@ __global__ __launch_bounds__(512, PASS == 2 ? 2 : 4) void attn_map_kernel(const 
     float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
     for (int j = 0; j < nt; ++j) {
       const int st = j % 3;
+      mf32x4 skv[4];
+      load_sk(j, skv);
       if (j + 2 < nt) dma_tile(j + 2, (j + 2) % 3);
       mf32x4 sacc[4][2];
-      s_tile(j, st, sacc);
+      s_tile(j, st, sacc, skv);
 #pragma unroll
       for (int nq = 0; nq < 2; ++nq) {
         float mx = sacc[0][nq][0];
@@ -280,10 +291,12 @@ __global__ __launch_bounds__(512, PASS == 2 ? 2 : 4) void attn_map_kernel(const 
     };
     for (int j = 0; j < nt; ++j) {
       const int st = j % 3;
+      mf32x4 skv[4];
+      load_sk(j, skv);
       if (j + 2 < nt) dma_tile(j + 2, (j + 2) % 3);
       if (j > 0) flush(j - 1);
       mf32x4 sacc[4][2];
-      s_tile(j, st, sacc);
+      s_tile(j, st, sacc, skv);
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
         mf32x4 cv;
@@ -299,6 +312,9 @@ __global__ __launch_bounds__(512, PASS == 2 ? 2 : 4) void attn_map_kernel(const 
         if (n16 == 0) *reinterpret_cast<mf32x4*>(cm + (j & 1) * 512 + wave * 64 + 16 * kb + 4 * pg) = cv;
       }
       wait_tile_ahead(j + 2 < nt);
+      // the column maxima above are handed to wave 0 through LDS across this barrier: make the write (and wave 0's reads of the
+      // slot it is about to be reused for) complete, not merely issued -- hipcc puts no lgkmcnt wait in front of a raw s_barrier
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
     flush(nt - 1);
@@ -333,9 +349,11 @@ __global__ __launch_bounds__(512, PASS == 2 ? 2 : 4) void attn_map_kernel(const 
         di[kb][e] = dinv[kc];
       }
     }
+    mf32x4 skv[4];
+    load_sk(j, skv);
     if (j + 2 < nt) dma_tile(j + 2, (j + 2) % 3);
     mf32x4 sacc[4][2];
-    s_tile(j, st, sacc);
+    s_tile(j, st, sacc, skv);
     mbf16x8 pf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)

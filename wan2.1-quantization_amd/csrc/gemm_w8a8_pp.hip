@@ -59,6 +59,9 @@ constexpr int PBUF = (PM + PN) * PK;  // one K-tile buffer: 64 KiB
 constexpr int PXB = PM * PK;          // offset of the W rows inside a buffer
 constexpr int PTURN = 2 * PBUF;       // eight 4-KiB turn buffers behind the ring
 constexpr int PLDS = PTURN + 8 * 4096;  // 160 KiB
+#if (defined(WANQ_PP_ABL_NODMA) || defined(WANQ_PP_ABL_NOREAD)) && !defined(WANQ_ALLOW_ABLATIONS)
+#error "WANQ_PP_ABL_* build deliberately wrong kernels (timing ablations): add -DWANQ_ALLOW_ABLATIONS, never in build.py's library"
+#endif
 #ifndef WANQ_PP_BURST
 #define WANQ_PP_BURST 32  // MFMAs per burst: 32 (two phases per K-tile, the shipped schedule) or 16 (four phases, the first form)
 #endif

@@ -253,6 +253,9 @@ __device__ __forceinline__ void hadamard_regs(float (&v)[KIN][EPL], int lane) { 
         }
   __builtin_amdgcn_sched_barrier(0);
   // ... then bits of c (lane bits 0 .. log2(LB)-1)
+#if (defined(WANQ_ROT_ABLATE_LANE) || defined(WANQ_ROT_ABLATE_MIX) || defined(WANQ_ROT_ABLATE_QUANT)) && !defined(WANQ_ALLOW_ABLATIONS)
+#error "WANQ_ROT_ABLATE_* build deliberately wrong kernels (timing ablations): add -DWANQ_ALLOW_ABLATIONS, never in build.py's library"
+#endif
 #ifndef WANQ_ROT_ABLATE_LANE  // (WANQ_ROT_ABLATE_*: timing probes only, tools/probes/rotate_ablate.py; never defined in the product build)
   lane_stage<1, KIN, EPL>(v, lane);
   lane_stage<2, KIN, EPL>(v, lane);

@@ -42,11 +42,18 @@ class ShardedBlocks:
         self.blocks, self.group, self.slots_fn = list(blocks), group, slots_fn
         self.P = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.P > 1 else 0
-        # a communicator of its own for the weight gathers (collective call: every rank of the default group builds its
-        # ShardedBlocks at the same point, as bench.py / quant_generate.py do); ranks and rank order are those of `group`
-        if gather_group is None and self.P > 1:
-            gather_group = dist.new_group(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD))
-        self.gather_group = gather_group if self.P > 1 else group
+        # A communicator of its own for the weight gathers, so that they do not queue behind the Ulysses all-to-alls of the block
+        # being computed.  dist.new_group is collective over WORLD, so it is only created implicitly when `group` IS the world
+        # (every rank builds its ShardedBlocks at the same point, as bench.py / quant_generate.py do); a proper subgroup must
+        # bring its own `gather_group` (or gets the shared one).  WANQ_FSDP_SHARED_GROUP=1 keeps the gathers on `group` itself:
+        # the two-communicator overlap has never run on real multi-rank RCCL from here, this is the fallback switch.
+        import os
+
+        if self.P > 1 and gather_group is None and os.environ.get("WANQ_FSDP_SHARED_GROUP", "0") != "1":
+            is_world = group is None or group is dist.group.WORLD or dist.get_world_size(group) == dist.get_world_size()
+            if is_world:
+                gather_group = dist.new_group(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD))
+        self.gather_group = gather_group if (self.P > 1 and gather_group is not None) else group
         first = slots_fn(self.blocks[0])
         self.layout = []  # (byte offset, nbytes, shape, dtype) per slot
         off = 0

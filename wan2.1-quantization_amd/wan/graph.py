@@ -5,7 +5,11 @@ addresses every time -- shapes are static and every temporary comes from torch's
 (conditional + unconditional) are captured once into a hipGraph and replayed: the host then spends one graph launch per step
 instead of ~1400 kernel launches (Python + ctypes + torch allocator calls), and the inter-kernel gaps shrink to the device's
 own dependent-launch latency.  The scheduler update stays outside (its coefficients and buffers change per step; it is one
-wanq_lincomb launch, wan/utils/fused_step.py).  Single-rank only: the sequence-parallel path issues collectives."""
+wanq_lincomb launch, wan/utils/fused_step.py).  Single-rank only: the sequence-parallel path issues collectives.
+
+The model's per-context cache (QuantWanModel._context_source: cross_attn.k / .v of a text context kept across steps) is OFF while
+the graph warms up and captures: the graph recomputes k / v from its own static context buffers on every replay, so it depends on
+no tensor the cache owns and `graph.ctx[i].copy_(new_context)` takes effect at the next replay."""
 import torch
 
 
@@ -17,17 +21,22 @@ class GraphedPasses:
         self.latent = latent.clone()
         self.t = torch.zeros(1, dtype=torch.int64, device=latent.device)
         self.ctx = [c.clone() for c in contexts]
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(warmup):  # lazy initialisation (rope tables, function attributes, split-KV workspaces) happens here
-                for c in self.ctx:
-                    model([self.latent], self.t, [c], seq_len)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
-            self.outs = [model([self.latent], self.t, [c], seq_len)[0] for c in self.ctx]
+        cache_was = getattr(model, "context_cache", True)
+        model.context_cache = False
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(warmup):  # lazy initialisation (rope tables, function attributes, split-KV workspaces) happens here
+                    for c in self.ctx:
+                        model([self.latent], self.t, [c], seq_len)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph), torch.no_grad():
+                self.outs = [model([self.latent], self.t, [c], seq_len)[0] for c in self.ctx]
+        finally:
+            model.context_cache = cache_was
 
     def __call__(self, latent, t):
         """-> list of model outputs (static buffers: consume them before the next call)."""

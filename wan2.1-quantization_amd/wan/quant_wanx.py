@@ -200,9 +200,12 @@ class QuantWanModel(WanModel, QuantModel):
         per live tensor: the entry holds the tensor itself (its storage cannot be recycled under the cache) and its in-place
         version counter; a different tensor, or the same one after an in-place write, recomputes.  At most four entries;
         `context_cache = False` (bench.py --no-context-cache) turns it off, anything that rebuilds the kernel-mode blocks
-        (hardware_forward_refactor, shard_blocks) empties it."""
+        (hardware_forward_refactor, shard_blocks) empties it.  Never used under graph capture (wan/graph.py turns it off for its
+        warm-up and capture as well): a captured graph must hold the cross_attn.k / .v launches itself -- it would otherwise bake in
+        pointers to tensors that only this cache owns (freed by the fifth other context or a rebuild of the blocks) and ignore
+        later in-place updates of its static context buffers."""
         src = lambda: _FpSrc(embedded.float().contiguous(), self.hip_blocks[0].act_dtype)  # noqa: E731
-        if not getattr(self, "context_cache", True):
+        if not getattr(self, "context_cache", True) or (embedded.is_cuda and torch.cuda.is_current_stream_capturing()):
             return src()
         cache = self.__dict__.setdefault("_ctx_cache", [])
         for ent in cache:
