@@ -17,25 +17,45 @@ import math
 import torch
 import torch.nn.functional as F
 
+# Evaluating this oracle ON THE GPU (whole-output block parity at the headline sizes, tests/test_gpu_fullsize.py): the functions
+# below take tensors of any device.  Two things differ there and are handled here so that the GPU evaluation is the same
+# function as the CPU one: torch's fp32 division on the GPU is not the correctly rounded quotient (tools/probes/vq_fullsize_diag.py:
+# 1.8e6 of 5e7 codes differ), so the quantisers' divisions go through fp64 and are rounded once to fp32 (`_div`; on the CPU the
+# plain fp32 division IS the IEEE quotient and stays as the reference writes it); and the Linears' fp32 matmuls run in fp64 there
+# (the sum of fp32 products, rounded once: closer to the exact value than any fp32 summation order, which is all the CPU result is).
+
+
+def _div(a, b):
+    if a.is_cuda:
+        b = torch.as_tensor(b, device=a.device)
+        return (a.double() / b.double()).float()
+    return a / b
+
+
+def _linear(x, w, b):
+    if x.is_cuda:
+        return F.linear(x.double(), w.double(), None if b is None else b.double()).float()
+    return F.linear(x, w, b)
+
 
 # ---------------------------------------------------------------- quantizers (torch restatement of qdiff_ref)
 def dyn_fake_quant(x, n_bits=8):
     """DynamicQuantizer.forward, sym (Q/base/base_quantizer.py:116-128,154-161).  x: [T, C] fp32."""
     n = 2 ** (n_bits - 1) - 1
-    delta = x.abs().amax(dim=1, keepdim=True) / n
+    delta = _div(x.abs().amax(dim=1, keepdim=True), float(n))
     delta = torch.where(delta < 1e-6, torch.full_like(delta, 1e-6), delta)
-    return torch.clamp(torch.round(x / delta), -n - 1, n) * delta
+    return torch.clamp(torch.round(_div(x, delta)), -n - 1, n) * delta
 
 
 def static_params(w, n_bits=8, sym=False):
     """StaticQuantizer.init_quant_params (Q/base/base_quantizer.py:70-99)."""
     if sym:
-        return (w.abs().amax(dim=1) / (2 ** (n_bits - 1) - 1)).unsqueeze(1), torch.zeros(w.shape[0], 1)
+        return _div(w.abs().amax(dim=1), float(2 ** (n_bits - 1) - 1)).unsqueeze(1), torch.zeros(w.shape[0], 1, device=w.device)
     n_levels = 2 ** n_bits
     hi = w.amax(dim=1).clamp_min(0.0)
     lo = w.amin(dim=1).clamp_max(0.0)
-    delta = (hi - lo) / (n_levels - 1)
-    zp = torch.round(lo / delta) + n_levels / 2
+    delta = _div(hi - lo, float(n_levels - 1))
+    zp = torch.round(_div(lo, delta)) + n_levels / 2
     return delta.unsqueeze(1), zp.unsqueeze(1)
 
 
@@ -43,7 +63,7 @@ def static_fake_quant(w, n_bits=8, sym=False):
     """StaticQuantizer.forward (Q/base/base_quantizer.py:56-68)."""
     delta, zp = static_params(w, n_bits, sym)
     n = (2 ** (n_bits - 1) - 1) if sym else 2 ** n_bits
-    q = torch.clamp(torch.round(w / delta) - zp, -n - 1, n)
+    q = torch.clamp(torch.round(_div(w, delta)) - zp, -n - 1, n)
     return (q + zp) * delta
 
 
@@ -57,14 +77,14 @@ class FakeQuantLinear:
         if channel_mask is None:
             self.weight = static_fake_quant(w, w_bits, w_sym)  # quant_layer.py:38-39
         else:  # viditq_quant_layer.py:40-50: quantise, rotate, quantise again
-            w1 = static_fake_quant(w / channel_mask.reshape(1, -1), w_bits, w_sym)
+            w1 = static_fake_quant(_div(w, channel_mask.reshape(1, -1)), w_bits, w_sym)
             self.weight = static_fake_quant((w1.double() @ rotation).float(), w_bits, w_sym)
         self.a_bits = a_bits
 
     def __call__(self, x):
         if self.mask is not None:  # viditq_quant_layer.py:62-63
             x = ((x * self.mask.reshape(1, -1)).double() @ self.R).float()
-        return F.linear(dyn_fake_quant(x, self.a_bits), self.weight, self.bias)
+        return _linear(dyn_fake_quant(x, self.a_bits), self.weight, self.bias)
 
 
 class FpLinear:
@@ -72,7 +92,7 @@ class FpLinear:
         self.weight, self.bias = weight.float(), None if bias is None else bias.float()
 
     def __call__(self, x):
-        return F.linear(x, self.weight, self.bias)
+        return _linear(x, self.weight, self.bias)
 
 
 # ---------------------------------------------------------------- FP pieces of the block
@@ -111,6 +131,10 @@ def attention(q, k, v, k_len=None):
     q [Lq, n, d], k/v [Lk, n, d]; keys at or beyond k_len are masked (k_lens, attention.py:78-80)."""
     if k_len is not None:
         k, v = k[:k_len], v[:k_len]
+    Lq, n, _ = q.shape
+    step = max(1, (1 << 29) // max(1, n * k.shape[0]))  # query chunks of <= 2 GiB of scores: rows are independent, same result
+    if Lq > step:
+        return torch.cat([attention(q[i:i + step], k, v) for i in range(0, Lq, step)])
     s = torch.einsum("qnd,knd->nqk", q, k) / math.sqrt(q.shape[-1])
     return torch.einsum("nqk,knd->qnd", torch.softmax(s, dim=-1), v)
 

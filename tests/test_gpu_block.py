@@ -480,3 +480,36 @@ def test_context_kv_cache_is_bit_equal_and_follows_the_context_tensor():
     model.context_cache = False
     y4_ref, _ = run(ctx_a)
     assert n_written == n_off and torch.equal(y4, y4_ref) and not torch.equal(y4, ya)
+
+
+def test_oracle_evaluated_on_the_gpu_is_the_cpu_oracle():
+    """oracle/wan_ref.py::BlockRef runs on either device (the whole-output parity tests of tests/test_gpu_fullsize.py evaluate it on
+    the GPU): same block, same inputs, both devices.  The quantiser divisions go through fp64 on the GPU precisely so that both
+    evaluations round the same quotients; what remains is fp32 summation order in LayerNorm / softmax in front of the quantisers,
+    i.e. the recipe's code-flip floor (tests/test_model_golden.py), and exact agreement of the fake-quantised weights."""
+    from oracle import wan_ref as wr
+
+    dim, heads, ffn, Lx, lc, grid = 256, 2, 512, 4 * 6 * 5, 12, (4, 6, 5)
+    g = torch.Generator().manual_seed(3)
+    sd = {}
+    for name in wr.LINEARS:
+        n_out, n_in = (ffn, dim) if name == "ffn.0" else (dim, ffn) if name == "ffn.2" else (dim, dim)
+        sd[name + ".weight"] = torch.randn(n_out, n_in, generator=g) / n_in ** 0.5
+        sd[name + ".bias"] = torch.randn(n_out, generator=g) * 0.05
+    for k in ("self_attn.norm_q", "self_attn.norm_k", "cross_attn.norm_q", "cross_attn.norm_k"):
+        sd[k + ".weight"] = torch.rand(dim, generator=g) + 0.5
+    sd["norm3.weight"], sd["norm3.bias"] = torch.rand(dim, generator=g) + 0.5, torch.randn(dim, generator=g) * 0.1
+    sd["modulation"] = torch.randn(1, 6, dim, generator=g) / dim ** 0.5
+    x, e0, ctx = torch.randn(Lx, dim, generator=g), torch.randn(1, 6, dim, generator=g) * 0.3, torch.randn(lc, dim, generator=g)
+    freqs = wr.rope_freqs(dim // heads)
+    cpu = wr.block_from_state(sd, heads, quant=True)
+    dev = wr.block_from_state({k: v.to(DEV) for k, v in sd.items()}, heads, quant=True)
+    for name in wr.LINEARS:
+        assert torch.equal(cpu.lin[name].weight, dev.lin[name].weight.cpu()), name  # static quantiser: identical on both devices
+    a = cpu(x, e0, grid, Lx, ctx, freqs)
+    b = dev(x.to(DEV), e0.to(DEV), grid, Lx, ctx.to(DEV), freqs.to(DEV)).cpu()
+    err = float((a.double() - b.double()).norm() / a.double().norm())
+    assert err < 5e-3, err
+    # the per-token quantiser alone, on identical inputs, IS identical (the division rule)
+    t = torch.randn(64, dim, generator=g) * torch.exp(torch.randn(dim, generator=g))
+    assert torch.equal(wr.dyn_fake_quant(t), wr.dyn_fake_quant(t.to(DEV)).cpu())
