@@ -226,7 +226,13 @@ def main():
         from wan.distributed.rehearsal import stage_collectives_through_host
         stage_collectives_through_host()
     elif world > 1:
-        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+        try:
+            dist.init_process_group("nccl", init_method="env://", device_id=dev)
+            dist.barrier()  # the communicator is created lazily: make a failure show here, with its reason, not inside the step
+        except Exception as e:  # one line, non-zero status (launch_ranks relays it); never a re-exec, never a silent fallback
+            print(f"bench.py rank {rank}/{world}: RCCL process group failed to initialise: {type(e).__name__}: {str(e).splitlines()[0] if str(e) else ''}",
+                  file=sys.stderr, flush=True)
+            sys.exit(3)
 
     from viditq_extension import qgemm
     from wan.configs import SIZE_CONFIGS, WAN_CONFIGS, latent_shape, seq_len_for
@@ -317,6 +323,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    a2a0 = (plan.sp.a2a_calls, plan.sp.a2a_bytes_sent)
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         latent = step(latent, i)
@@ -324,6 +331,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    a2a = ((plan.sp.a2a_calls - a2a0[0]) / args.steps, (plan.sp.a2a_bytes_sent - a2a0[1]) / args.steps)
     if world > 1:
         tmax = torch.tensor([dt], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -363,7 +371,10 @@ def main():
                                                              "of_MB": round(len(sharded.blocks) * sharded.full_bytes / 1e6, 1)},
                    "launch": "hip graph replay of the two DiT passes + 1 fused CFG/scheduler kernel" if graphed is not None else
                              "eager launches + 1 fused CFG/scheduler kernel",
-                   "rccl_ranks": dist.get_world_size() if world > 1 else 1},
+                   "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                   # Ulysses exchange of THIS rank inside the timed region (wan/distributed/parallel.py counts what it hands to
+                   # all_to_all_single): bytes leaving the GPU over xGMI per step, and the number of all-to-alls
+                   "a2a_per_step": int(a2a[0]), "a2a_bytes_per_step": int(a2a[1])},
     }
     # Two MFMA-bound kernels carry the step: the bf16 flash attention (the dominant one at L = 32760) and the int8 GEMM
     # behind every W8A8 Linear.  `roofline` is whichever took more of the timed region; the other is reported beside it.
@@ -377,7 +388,7 @@ def main():
         a_traffic, a_src = None, a_src + " was taken on the bf16 attention kernel, not on this run's attention configuration"
     if gs:
         ach = gs["ops"] / gs["seconds"]
-        lines.append({"bound": "mfma", "kernel": "gemm_w8a8_big_kernel / gemm_w8a8_kernel (int8 MFMA, every W8A8 linear)",
+        lines.append({"bound": "mfma", "kernel": "gemm_w8a8_pp_kernel (ping-pong persistent, W8) / gemm_w8a8_big_kernel (W4, GELU or 16-bit residual forms) / gemm_w8a8_kernel (small shapes): int8 MFMA, every quantised linear",
                       "achieved": ach / 1e12, "peak": INT8_MFMA_PEAK / 1e12, "unit": "TOP/s", "frac": ach / INT8_MFMA_PEAK,
                       "traffic": g_traffic, "traffic_source": g_src, "traffic_unit": "HBM bytes per launch (PMC)", "launches": gs["launches"],
                       "avg_launch_us": gs["seconds"] / gs["launches"] * 1e6, "share_of_step": gs["seconds"] / dt_prof})

@@ -59,6 +59,37 @@ def main():
         if isinstance(mod, QuantizedLinear) and (mod.uses_mask or mod.uses_rotation):
             calib.init_rotation_and_channel_mask_(mod, name, calib_data, gen)
     model.set_init_done()
+
+    if os.environ.get("WANQ_REHEARSE_FP") == "1":
+        # ---- Ulysses for the FP model, the calibration reduction and simulation mode: WanModel.forward(..., sp)
+        # on the HIP attention kernel, two ranks on the one GPU.  The FP Linears are torch / hipBLASLt bf16 GEMMs whose kernel
+        # choice depends on M, so a token shard is not bit-equal to the full sequence: the bar is the bf16 rounding level.
+        plan = ParallelPlan(world, rank, 1, world)
+        sl, sl1 = seq_len_for(shape, sp_size=world), seq_len_for(shape)
+
+        def rel(a, b):
+            return ((a.float() - b.float()).norm() / b.float().norm()).item()
+
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            ref = fp([latent], t, [ctx_c], sl1)[0]
+            hooks1 = calib.add_hooks(fp)
+            fp([latent], t, [ctx_c], sl1)
+            want = {n: h.running.clone() for n, h in hooks1.items()}
+            for h in hooks1.values():
+                h.hook_handle.remove()
+            hooks2 = calib.add_hooks(fp)
+            out = fp([latent], t, [ctx_c], sl, plan.sp)[0]
+            got = calib.gather_and_save_activation(hooks2)
+            sim_ref = model([latent], t, [ctx_c], sl1)[0]          # simulation mode (hip_blocks is None): fake-quant Linears
+            sim = model([latent], t, [ctx_c], sl, plan.sp)[0]
+        e_fp, e_sim = rel(out, ref), rel(sim, sim_ref)
+        e_cal = max(((got[n][0].to(dev) - want[n]).abs().max() / want[n].abs().max().clamp_min(1e-6)).item() for n in want)
+        torch.cuda.synchronize()
+        print(f"RANK {rank} fp_sp_rel={e_fp:.3e} sim_sp_rel={e_sim:.3e} calib_max_rel={e_cal:.3e} layers={len(want)}", flush=True)
+        assert e_fp < 1e-2 and e_sim < 2e-2 and e_cal < 2e-2, (e_fp, e_sim, e_cal)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     model.hardware_forward_refactor()
 
     model([latent], t, [ctx_c], seq_len_for(shape))  # warm-up: library heuristics / lazy initialisation settle here

@@ -326,3 +326,190 @@ def _q8_exchange_worker(rank, world, port, q):
 
 def test_int8_qk_exchange_layout_world2():
     _run(_q8_exchange_worker, 2, 29693)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Ulysses for the FP model and the calibration reduction (the reference patches usp_attn_forward / usp_dit_forward onto the FP
+# model, W/wan/text2video.py:89-100, and get_calib_data_wanx.py runs under it): WanModel.forward(..., sp) under gloo.  The
+# attention core is the HIP kernel in the product; here -- CPU, test only -- wan.ops.attention is replaced by the oracle's fp32
+# softmax definition, everything else (sharding, per-rank rotary slice, head exchange, final all-gather, hooks) is product code.
+def _fp_ulysses_worker(rank, world, port, q):
+    try:
+        _init(rank, world, port)
+        from oracle import wan_ref as wr
+        from wan import calib, ops
+        from wan.configs import seq_len_for
+        from wan.distributed.parallel import SeqParallel
+        from wan.modules.model import WanModel
+
+        def attention_ref(q_, k_, v_, num_heads, k_len=None, **kw):
+            d = q_.shape[1] // num_heads
+            o = wr.attention(q_.float().view(-1, num_heads, d), k_.float().view(-1, num_heads, d), v_.float().view(-1, num_heads, d), k_len)
+            return o.reshape(q_.shape[0], -1)  # fp32: no autocast on the CPU for the o projection behind it
+
+        ops.attention = attention_ref
+        calib.fused.col_absmax_ = lambda running, x: running.copy_(torch.maximum(running, x.float().abs().amax(0)))
+        torch.manual_seed(0)
+        heads = 4
+        model = WanModel(dim=64, ffn_dim=128, num_heads=heads, num_layers=2, text_dim=32, freq_dim=32).eval()
+        g = torch.Generator().manual_seed(1)
+        torch.nn.init.xavier_uniform_(model.head.head.weight, generator=g)
+        shape = (16, 3, 6, 10)  # 3 * 3 * 5 = 45 tokens: padded to a multiple of the world size, odd per-rank tails
+        latent = torch.randn(shape, generator=g)
+        ctx = torch.randn(7, 32, generator=g) * 0.1
+        t = torch.tensor([321])
+        sp = SeqParallel(None)
+        sl = seq_len_for(shape, sp_size=world)
+        assert sl % world == 0 and sl >= 45
+        with torch.no_grad():
+            ref = model([latent], t, [ctx], sl)[0]
+            hooks_ref = calib.add_hooks(model)
+            model([latent], t, [ctx], sl)
+            want = {n: h.running.clone() for n, h in hooks_ref.items()}
+            for h in hooks_ref.values():
+                h.hook_handle.remove()
+            hooks = calib.add_hooks(model)
+            out = model([latent], t, [ctx], sl, sp)[0]
+        torch.testing.assert_close(out, ref, rtol=2e-4, atol=2e-5)
+        got = calib.gather_and_save_activation(hooks)  # MAX all-reduce over the ranks' token shards
+        assert set(got) == set(want)
+        for n in want:
+            # padded rows are zeros in front of the first block only; behind it they carry bias terms on BOTH paths
+            torch.testing.assert_close(got[n][0], want[n], rtol=2e-4, atol=2e-5, msg=n)
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_fp_model_and_calibration_under_ulysses_world2():
+    _run(_fp_ulysses_worker, 2, 29641)
+
+
+def test_fp_model_and_calibration_under_ulysses_world4():
+    _run(_fp_ulysses_worker, 4, 29642)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs 4 and 5 at world size 8 (gloo): the EXACT plan objects `bench.py --preset 14B-ulysses` / `--preset 14B-w4a8-fsdp`
+# build -- Ulysses degree 8 on 40 heads, 9450 tokens and 5 heads per rank, the head chunks of the pipelined exchange and their
+# packed send images; the --dit_fsdp shard layout of a block with the 14B weight shapes (FFN weights packed 4-bit) -- so that the
+# first real 8-GPU run meets no layout it has not seen.
+def _preset_ulysses_worker(rank, world, port, q):
+    try:
+        _init(rank, world, port)
+        from wan.configs import SIZE_CONFIGS, WAN_CONFIGS, latent_shape, seq_len_for
+        from wan.distributed.parallel import ParallelPlan
+        from wan.quant_wanx_hip import _head_chunks
+
+        cfg = WAN_CONFIGS["t2v-14B"]
+        H, C = cfg["num_heads"], cfg["dim"]
+        d = C // H
+        plan = ParallelPlan(world, rank, *ParallelPlan.choose(world, H, False))  # bench.py: --no-cfg-parallel under the preset
+        assert plan.describe() == "cfg1xsp8" and plan.sp.size == 8 and plan.sp.rank == rank and plan.cfg_degree == 1
+        shape = latent_shape(SIZE_CONFIGS["1280*720"], 81)
+        assert tuple(shape) == (16, 21, 90, 160)
+        seq_len = seq_len_for(shape, sp_size=plan.sp_degree)
+        lp = seq_len // world
+        assert seq_len == 75600 and lp == 9450
+        chunks = _head_chunks(H // world, seq_len, torch.device("cpu"))
+        assert chunks == [(0, 1), (1, 2), (2, 4), (4, 5)]  # a head is 296 workgroups > 256 CUs: units of one head, 1 + 1 + 2 + 1
+        cols = [(a * d, b * d) for a, b in chunks]
+        numel, hmap, where = plan.sp.packed_layout(lp, C, d, cols, torch.device("cpu"))
+        assert numel == lp * C and hmap.shape == (H, 2)
+        assert where == [(world * lp * c0, c1 - c0) for c0, c1 in cols]
+        # head h of the local [lp, C] tensor: destination rank h // 5, column (h % 5) * d inside that rank's head group
+        for h in (0, 4, 5, 17, 39):
+            r, cc = divmod(h * d, C // world)
+            c0, c1 = next(ch for ch in cols if ch[0] <= cc < ch[1])
+            assert hmap[h].tolist() == [world * lp * c0 + r * lp * (c1 - c0) + (cc - c0), c1 - c0]
+        # one exchange at the preset's per-rank size through the packed images (int8 stand-in for the bf16 payload: the layout
+        # code never looks at the dtype), against the transpose-pack form chunk by chunk
+        g = torch.Generator().manual_seed(rank)
+        x = torch.randint(-128, 128, (lp, C), generator=g, dtype=torch.int8)
+        flat = torch.empty(numel, dtype=torch.int8)
+        for h in range(H):  # what rmsnorm_rope_scatter writes: head h's [lp, d] block at (offset, row stride)
+            off, stride = hmap[h].tolist()
+            flat.as_strided((lp, d), (stride, 1), off).copy_(x[:, h * d:(h + 1) * d])
+        for (c0, c1), (off, w) in zip(cols, where):
+            got = plan.sp.scatter_packed(flat, lp, off, w)
+            want = plan.sp.scatter_heads(x, cols=(c0, c1))
+            assert got.shape == (seq_len, c1 - c0) and torch.equal(got, want)
+        assert plan.sp.a2a_calls == 8 and plan.sp.a2a_bytes_sent == 2 * lp * (C // world) * world * 7 // 8
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_preset_14b_ulysses_plan_world8():
+    _run(_preset_ulysses_worker, 8, 29651)
+
+
+class _Preset14BBlock:
+    """Weight slots of one kernel-mode 14B block under quant_configs/w4a8_mixed.yaml: attention projections int8 [5120, 5120], FFN
+    weights packed 4-bit (uint8 [N, K / 2])."""
+
+    def __init__(self, seed):
+        g = torch.Generator().manual_seed(seed)
+        C, F = 5120, 13824
+
+        def w(n, k, packed):
+            t = torch.empty(n, k // 2 if packed else k, dtype=torch.uint8 if packed else torch.int8)
+            t.view(torch.uint8)[::997, ::13] = torch.randint(0, 256, t[::997, ::13].shape, generator=g, dtype=torch.uint8)  # sparse marks
+            return t
+
+        self.self_attn, self.cross_attn = _ToyAttn.__new__(_ToyAttn), _ToyAttn.__new__(_ToyAttn)
+        for a in (self.self_attn, self.cross_attn):
+            for l in "qkvo":
+                setattr(a, l, _ToyLin(w(C, C, False)))
+        self.ffn0, self.ffn2 = _ToyLin(w(F, C, True)), _ToyLin(w(C, F, True))
+
+    def marks(self):
+        out = []
+        for a in (self.self_attn, self.cross_attn):
+            for l in "qkvo":
+                out.append(getattr(a, l).weight.view(torch.uint8)[::997, ::13].clone())
+        return out + [self.ffn0.weight[::997, ::13].clone(), self.ffn2.weight[::997, ::13].clone()]
+
+
+def _preset_fsdp_worker(rank, world, port, q):
+    try:
+        _init(rank, world, port)
+        from wan.distributed.fsdp import ShardedBlocks
+
+        blk = _Preset14BBlock(0)  # every rank builds the same block (as every rank loads the same checkpoint)
+        want = blk.marks()
+        C, F = 5120, 13824
+        sizes = [C * C] * 8 + [F * C // 2, C * F // 2]
+        sh = ShardedBlocks([blk], None)
+        assert sh.P == 8 and [nb for _, nb, _, _ in sh.layout] == sizes
+        offs = [o for o, _, _, _ in sh.layout]
+        assert offs == [sum(sizes[:i]) for i in range(10)]  # every slot is a multiple of 16 B: no padding between slots
+        assert sh.full_bytes == sum(sizes) and sh.full_bytes % (16 * 8) == 0 and sh.shard_bytes == sh.full_bytes // 8 == 35061760
+        assert sh.bytes_per_rank() == sh.shard_bytes + 2 * sh.full_bytes
+        assert blk.ffn0.weight.numel() == 0
+        got = []
+        sh.run(lambda b: got.extend(b.marks()))  # one all-gather of 280 MB over the 8 ranks, views handed back to the block
+        assert len(got) == len(want) and all(torch.equal(a, b) for a, b in zip(got, want))
+        assert blk.self_attn.q.weight.numel() == 0  # released after use
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_preset_14b_w4a8_fsdp_shard_layout_world8():
+    _run(_preset_fsdp_worker, 8, 29652)

@@ -112,3 +112,35 @@ def test_quant_generate_two_ranks_ulysses_and_dit_fsdp(tmp_path):
     one = torch.load(tmp_path / "one.pt", weights_only=True)
     two = torch.load(tmp_path / "two.pt", weights_only=True)
     assert torch.equal(one, two)
+
+
+def test_fp_generate_and_calibration_two_ranks_ulysses(tmp_path):
+    """`fp_generate.py --ulysses_size 2` and `get_calib_data_wanx.py --ulysses_size 2` under two ranks (one-GPU rehearsal): the FP
+    latent and the calibration file against the single-rank runs of the same scripts (bf16 GEMMs on token shards: close, not
+    bit-equal), and the sharded calibration file feeding ptq_wanx.py."""
+    import socket
+
+    qc = os.path.join(PKG, "quant_configs", "w8a8_all_linears.yaml")
+    run("fp_generate.py", "--save_file", str(tmp_path / "fp_one.pt"), cwd=tmp_path)
+    run("get_calib_data_wanx.py", "--quant_config", qc, "--calib_data", str(tmp_path / "calib_one.pth"), cwd=tmp_path)
+
+    def two_ranks(script, *extra):
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(PKG, script), "--task", "t2v-1.3B", "--size", "832*480", "--frame_num", "5",
+               "--num_layers", "2", "--sample_steps", "2", "--base_seed", "42", "--output_dir", str(tmp_path), "--ulysses_size", "2", *extra]
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp_path, timeout=600,
+                           env=dict(os.environ, OMP_NUM_THREADS="4", WANQ_REHEARSE_ON_ONE_GPU="1"))
+        assert r.returncode == 0, f"two-rank {script} failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+
+    two_ranks("fp_generate.py", "--save_file", str(tmp_path / "fp_two.pt"))
+    one, two = torch.load(tmp_path / "fp_one.pt", weights_only=True), torch.load(tmp_path / "fp_two.pt", weights_only=True)
+    assert one.shape == two.shape and float((one - two).norm() / one.norm()) < 2e-2
+    two_ranks("get_calib_data_wanx.py", "--quant_config", qc, "--calib_data", str(tmp_path / "calib_two.pth"))
+    c1, c2 = torch.load(tmp_path / "calib_one.pth", weights_only=True), torch.load(tmp_path / "calib_two.pth", weights_only=True)
+    assert set(c1) == set(c2) and len(c1) > 20
+    worst = max(float(((c1[k] - c2[k]).abs().max() / c1[k].abs().max().clamp_min(1e-6))) for k in c1)
+    assert worst < 5e-2, worst
+    run("ptq_wanx.py", "--quant_config", qc, "--calib_data", str(tmp_path / "calib_two.pth"), cwd=tmp_path)

@@ -63,6 +63,18 @@ def test_two_ranks_int8_qk_under_ulysses():
     assert r.stdout.count("fsdp_rel=0.000e+00") == 2, r.stdout[-2000:]
 
 
+def test_two_ranks_fp_model_calibration_and_simulation_mode_under_ulysses():
+    """Ulysses for the FP model (fp_generate.py / get_calib_data_wanx.py --ulysses_size P) and for simulation mode
+    (quant_generate.py --hardware false): two ranks on the one GPU through the HIP attention kernel against the single-rank run;
+    the hooks' per-channel maxima after the MAX all-reduce against the single-rank hooks."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(HERE, "sp_rehearsal_worker.py")]
+    env = dict(os.environ, OMP_NUM_THREADS="4", WANQ_REHEARSE_FP="1")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, f"FP Ulysses rehearsal failed:\n{r.stdout[-4000:]}\n{r.stderr[-4000:]}"
+    assert r.stdout.count("fp_sp_rel=") == 2, r.stdout[-2000:]
+
+
 @pytest.mark.parametrize("gpus,plan,extra,launcher", [
     (2, "cfg2xsp1", [], "self"),  # `python bench.py --gpus 2`, the form the driver uses at N = 1: bench.py starts its own ranks
     (4, "cfg2xsp2", [], "torchrun"),

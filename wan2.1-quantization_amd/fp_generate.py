@@ -19,7 +19,6 @@ def generate(args):
     cfg = cli.model_config(args)
     rank, world, local, plan = cli.setup_distributed(args, cfg["num_heads"])
     cli.init_logging(rank)
-    assert plan.sp_degree == 1, "the FP path runs without sequence parallelism (use --cfg_parallel for 2 GPUs)"
     t2v = WanT2V(cfg, args.ckpt_dir, device_id=local, rank=rank, t5_fsdp=args.t5_fsdp, dit_fsdp=args.dit_fsdp,
                  t5_cpu=args.t5_cpu, plan=plan, context_file=args.context_file)
     os.makedirs(args.output_dir, exist_ok=True)

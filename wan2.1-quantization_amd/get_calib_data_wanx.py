@@ -21,11 +21,19 @@ def main(args):
     cli.init_logging(rank)
     quant_config = qcfg.load(args.quant_config)
     save_path = args.calib_data or quant_config.calib_data.save_path
-    t2v = WanT2V(cfg, args.ckpt_dir, device_id=local, rank=rank, plan=None, context_file=args.context_file)
+    # --ulysses_size P (get_calib_data_wanx.py:455-473 runs under the reference's USP patch): the P ranks of a sequence-parallel
+    # group run ONE prompt on token shards (each hook sees its shard's rows); without it every rank runs its own prompts.  Either
+    # way the per-channel maxima of all ranks are MAX-reduced at the end, which is what the reference's concatenation + ptq's
+    # .max(dim=0) amounts to.
+    sharded = args.ulysses_size > 1
+    t2v = WanT2V(cfg, args.ckpt_dir, device_id=local, rank=rank, plan=plan if sharded else None, context_file=args.context_file)
     hooks = calib.add_hooks(t2v.model, torch.nn.Linear)
     logging.info("hooked %d Linear layers", len(hooks))
     prompts = cli.read_prompts(args)
-    mine = prompts[rank::world] or prompts[:1]  # prompts are data-parallel over ranks; the masks are MAX-reduced
+    if sharded:
+        mine = prompts  # world = ulysses_size (x 2 with CFG parallelism): one group, every prompt
+    else:
+        mine = prompts[rank::world] or prompts[:1]  # prompts are data-parallel over ranks; the masks are MAX-reduced
     for prompt in mine:
         t2v.generate(prompt, size=SIZE_CONFIGS[args.size], frame_num=args.frame_num, shift=args.sample_shift,
                      sample_solver=args.sample_solver, sampling_steps=args.sample_steps, guide_scale=args.sample_guide_scale,

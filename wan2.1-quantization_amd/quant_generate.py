@@ -44,8 +44,7 @@ def main(args):
             sh = model.shard_blocks(None)
             logging.info("dit_fsdp: %.1f MB of block weights per rank (of %.1f MB)", sh.bytes_per_rank() / 1e6,
                          len(sh.blocks) * sh.full_bytes / 1e6)
-    else:
-        assert plan.sp_degree == 1, "sequence parallelism needs kernel mode"
+    # (simulation mode, --hardware false, shards through the FP model's Ulysses path: its fake-quant Linears are token-local)
     t2v = WanT2V(cfg, device_id=local, rank=rank, model=model.eval(), plan=plan, context_file=args.context_file)
     os.makedirs(args.output_dir, exist_ok=True)
     for i, prompt in enumerate(cli.read_prompts(args)):

@@ -47,6 +47,12 @@ class SeqParallel:
         self.group = group
         self.size = dist.get_world_size(group) if (dist.is_initialized() and group is not False) else 1
         self.rank = dist.get_rank(group) if self.size > 1 else 0
+        # all-to-all accounting (bench.py reports it per step): calls and bytes this rank sends to OTHER ranks
+        self.a2a_calls, self.a2a_bytes_sent = 0, 0
+
+    def _count(self, send):
+        self.a2a_calls += 1
+        self.a2a_bytes_sent += send.numel() * send.element_size() * (self.size - 1) // self.size
 
     # ---- sequence sharding ------------------------------------------------------------------------
     def padded_len(self, L):
@@ -82,6 +88,7 @@ class SeqParallel:
         w = send.shape[2]
         send = send.transpose(0, 1).contiguous()  # [P, Lp, w]: block r goes to rank r
         recv = torch.empty_like(send)
+        self._count(send)
         work = dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)
         post = lambda r: r.view(P * lp, w)  # noqa: E731  blocks arrive in rank order == sequence order
         return _Pending(work, recv, post) if async_op else post(recv)
@@ -112,6 +119,7 @@ class SeqParallel:
         P = self.size
         send = flat[off:off + P * lp * w].view(P, lp, w)
         recv = torch.empty_like(send)
+        self._count(send)
         work = dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)
         post = lambda r: r.view(P * lp, w)  # noqa: E731
         return _Pending(work, recv, post) if async_op else post(recv)
@@ -129,6 +137,7 @@ class SeqParallel:
         lp = l // P
         send = x.contiguous().view(P, lp, w)  # block r = tokens of rank r
         recv = torch.empty_like(send)
+        self._count(send)
         work = dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)
         if out is None:
             post = lambda r: r.transpose(0, 1).reshape(lp, P * w)  # noqa: E731  block s = head group s

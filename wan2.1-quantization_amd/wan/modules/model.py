@@ -32,19 +32,22 @@ def rope_params(max_seq_len, dim, theta=10000):
     return torch.polar(torch.ones_like(ang), ang)
 
 
-def rope_apply(x, grid, freqs):
+def rope_apply(x, grid, freqs, offset=0):
     """Reference-semantics rotary embedding in float64 for ONE sample: x [L, n, d]; rows beyond f*h*w are
     passed through (reference model.py:43-70).  Used by the FP torch path; the HIP path uses
-    ops.rmsnorm_rope_ with ops.rope_table."""
+    ops.rmsnorm_rope_ with ops.rope_table.  `offset`: x holds rows offset .. offset + L of the sequence (a rank's token shard
+    under Ulysses: the reference slices the frequency table per rank, wan/distributed/xdit_context_parallel.py:52-58)."""
     f, h, w = grid
     n_tok = f * h * w
     c = x.shape[-1] // 2
     parts = freqs.split([c - 2 * (c // 3), c // 3, c // 3], dim=1)
     fi = torch.cat([parts[0][:f].view(f, 1, 1, -1).expand(f, h, w, -1), parts[1][:h].view(1, h, 1, -1).expand(f, h, w, -1),
-                    parts[2][:w].view(1, 1, w, -1).expand(f, h, w, -1)], dim=-1).reshape(n_tok, 1, c).to(x.device)
-    xc = torch.view_as_complex(x[:n_tok].to(torch.float64).reshape(n_tok, x.shape[1], c, 2))
+                    parts[2][:w].view(1, 1, w, -1).expand(f, h, w, -1)], dim=-1).reshape(n_tok, 1, c)
+    real = max(0, min(x.shape[0], n_tok - offset))  # rows of x that are real tokens
+    fi = fi[offset:offset + real].to(x.device)
+    xc = torch.view_as_complex(x[:real].to(torch.float64).reshape(real, x.shape[1], c, 2))
     out = torch.view_as_real(xc * fi).flatten(2)
-    return torch.cat([out, x[n_tok:].to(torch.float64)]).float()
+    return torch.cat([out, x[real:].to(torch.float64)]).float()
 
 
 class WanRMSNorm(nn.Module):
@@ -76,16 +79,28 @@ class WanSelfAttention(nn.Module):
         self.norm_q = WanRMSNorm(dim, eps=eps) if qk_norm else nn.Identity()
         self.norm_k = WanRMSNorm(dim, eps=eps) if qk_norm else nn.Identity()
 
-    def forward(self, x, seq_lens, grid_sizes, freqs):
+    def forward(self, x, seq_lens, grid_sizes, freqs, sp=None):
+        """sp: wan.distributed.parallel.SeqParallel or None.  Under Ulysses x is this rank's token shard [1, L/P, C]: q, k, v are
+        projected and rotated locally (the rank's slice of the rotary table), exchanged head-scatter / sequence-gather, the
+        attention runs on H/P heads over the whole sequence, and the output comes back (usp_attn_forward,
+        W/wan/distributed/xdit_context_parallel.py:149-192)."""
         b, s, n, d = x.shape[0], x.shape[1], self.num_heads, self.head_dim
         q = self.norm_q(self.q(x)).view(b, s, n, d)
         k = self.norm_k(self.k(x)).view(b, s, n, d)
         v = self.v(x).view(b, s, n, d)
+        par = sp is not None and sp.size > 1
         outs = []
         for i in range(b):
-            qi = rope_apply(q[i], grid_sizes[i], freqs).to(torch.bfloat16).flatten(1)
-            ki = rope_apply(k[i], grid_sizes[i], freqs).to(torch.bfloat16).flatten(1)
-            outs.append(ops.attention(qi, ki, v[i].to(torch.bfloat16).flatten(1), n, int(seq_lens[i])))
+            off = sp.rank * s if par else 0
+            qi = rope_apply(q[i], grid_sizes[i], freqs, off).to(torch.bfloat16).flatten(1)
+            ki = rope_apply(k[i], grid_sizes[i], freqs, off).to(torch.bfloat16).flatten(1)
+            vi = v[i].to(torch.bfloat16).flatten(1)
+            if par:
+                wq, wk, wv = (sp.scatter_heads(t_, async_op=True) for t_ in (qi, ki, vi))
+                oi = ops.attention(wq.wait(), wk.wait(), wv.wait(), n // sp.size, int(seq_lens[i]))
+                outs.append(sp.gather_heads(oi))
+            else:
+                outs.append(ops.attention(qi, ki, vi, n, int(seq_lens[i])))
         return self.o(torch.stack(outs))
 
 
@@ -114,11 +129,12 @@ class WanAttentionBlock(nn.Module):
         self.ffn = nn.Sequential(nn.Linear(dim, ffn_dim), nn.GELU(approximate="tanh"), nn.Linear(ffn_dim, dim))
         self.modulation = nn.Parameter(torch.randn(1, 6, dim) / dim ** 0.5)
 
-    def forward(self, x, e, seq_lens, grid_sizes, freqs, context, context_lens):
-        """x [B, L, C] fp32 residual stream, e [B, 6, C] fp32 (reference model.py:293-370)."""
+    def forward(self, x, e, seq_lens, grid_sizes, freqs, context, context_lens, sp=None):
+        """x [B, L, C] fp32 residual stream (a token shard under Ulysses: everything but the self-attention is token-local),
+        e [B, 6, C] fp32 (reference model.py:293-370)."""
         with torch.autocast("cuda", enabled=False):
             e = (self.modulation.float() + e.float()).chunk(6, dim=1)
-        y = self.self_attn(self.norm1(x).float() * (1 + e[1]) + e[0], seq_lens, grid_sizes, freqs)
+        y = self.self_attn(self.norm1(x).float() * (1 + e[1]) + e[0], seq_lens, grid_sizes, freqs, sp)
         x = x + y.float() * e[2]
         x = x + self.cross_attn(self.norm3(x), context, context_lens).float()
         y = self.ffn(self.norm2(x).float() * (1 + e[4]) + e[3])
@@ -201,12 +217,22 @@ class WanModel(nn.Module):
             out.append(u.reshape(c, *[i * j for i, j in zip(g, self.patch_size)]))
         return out
 
-    def forward(self, x, t, context, seq_len):
+    def forward(self, x, t, context, seq_len, sp=None):
+        """sp: SeqParallel or None.  Ulysses as the reference patches it onto the FP model (usp_dit_forward,
+        W/wan/distributed/xdit_context_parallel.py:66-146; W/wan/text2video.py:89-100): the token sequence (padded to a multiple
+        of P by seq_len) is cut into P contiguous shards after the embedding, every block runs on its shard, the head output is
+        all-gathered in rank order and unpatchified on every rank."""
         x, e, e0, context, seq_lens, grid_sizes = self.embed(x, t, context, seq_len)
         x = x.float()
+        par = sp is not None and sp.size > 1
+        if par:
+            assert x.shape[0] == 1 and x.shape[1] % sp.size == 0, "Ulysses: batch 1, seq_len a multiple of the degree"
+            x = sp.shard_rows(x[0]).unsqueeze(0).contiguous()
         for block in self.blocks:
-            x = block(x, e0, seq_lens, grid_sizes, self.freqs, context, None)
+            x = block(x, e0, seq_lens, grid_sizes, self.freqs, context, None, sp if par else None)
         x = self.head(x, e)
+        if par:
+            x = sp.all_gather_rows(x[0].contiguous()).unsqueeze(0)
         return [u.float() for u in self.unpatchify(x, grid_sizes)]
 
     def init_weights(self):

@@ -219,9 +219,8 @@ class QuantWanModel(WanModel, QuantModel):
 
     @torch.no_grad()
     def forward(self, x, t, context, seq_len, sp=None):
-        if self.hip_blocks is None:
-            assert sp is None or sp.size == 1, "sequence parallelism is wired for kernel mode"
-            return WanModel.forward(self, x, t, context, seq_len)
+        if self.hip_blocks is None:  # simulation mode: the fake-quant Linears are token-local, the FP model's Ulysses path applies
+            return WanModel.forward(self, x, t, context, seq_len, sp)
         outs = []
         for xi, ci, ti in zip(x, context, t.reshape(-1, 1)):
             with torch.autocast("cuda", enabled=False):
