@@ -40,7 +40,7 @@ def main():
         wtr.writerow(["launch", "M", "N", "K", "out", "gelu", "gate_res", "algorithmic_read_MB", "FETCH_SIZE_x2_MB",
                       "algorithmic_write_MB", "WRITE_SIZE_MB"])
         wtr.writerows(out_rows)
-    summary = {"kernel": "gemm_w8a8_big_kernel", "launches": len(LAUNCHES),
+    summary = {"kernel": "gemm_w8a8_pp_kernel (fp32 + gate + residual, 16-bit) / gemm_w8a8_big_kernel", "launches": len(LAUNCHES),
                "hbm_bytes_per_launch": tot_hbm / len(LAUNCHES), "algorithmic_bytes_per_launch": tot_alg / len(LAUNCHES),
                # which bench.py workload the launches belong to (bench.py reports the figure only for that workload) and which
                # code they were taken on
