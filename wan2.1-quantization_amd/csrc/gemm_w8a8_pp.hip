@@ -524,6 +524,9 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_pp_kernel(const GemmParams p
       while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
     }
   }
+#ifdef WANQ_PP_JITTER
+  unsigned pp_jit = 0x9e3779b9u * (unsigned)(wave + 1) + blockIdx.x * 7919u;
+#endif
   uint32_t bC = 0;
   // vector-memory wait at the end of a load phase: all but the pieces of the five youngest load phases (10), plus the store
   // instructions of the epilogue while they are younger than the oldest of those phases (vm_left phases, vm_mode: 1 = 16 stores,
@@ -540,9 +543,21 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_pp_kernel(const GemmParams p
       asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                          \
     }                                                                            \
   } while (0)
+#ifdef WANQ_PP_JITTER  // race screen (diagnostic build, correct results): every wave idles a pseudo-random 0-1500 cycles in front of every
+  // barrier, so that no ordering holds merely because the waves run in lock-step (tools/ab_gemm_variants.py must stay bit-equal)
+#define PP_JIT()                                                                                   \
+  do {                                                                                             \
+    pp_jit = pp_jit * 1664525u + 1013904223u;                                                      \
+    const unsigned n_ = __builtin_amdgcn_readfirstlane((pp_jit >> 24) & 15u);                      \
+    for (unsigned i_ = 0; i_ < n_; ++i_) __builtin_amdgcn_s_sleep(1);                              \
+  } while (0)
+#else
+#define PP_JIT() do { } while (0)
+#endif
 #define PP_BAR()                         \
   do {                                   \
     __builtin_amdgcn_sched_barrier(0);   \
+    PP_JIT();                            \
     __builtin_amdgcn_s_barrier();        \
     __builtin_amdgcn_sched_barrier(0);   \
   } while (0)
@@ -619,6 +634,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_pp_kernel(const GemmParams p
       // their barrier, not behind it.
       const bool sc_now = OUT != WANQ_I32 && fast_scales && kt == nk - 2;
       // phase A
+      PP_JIT();
       PP_READ_X(0);
       PP_READ_W(wfa, 0);
       PP_READ_W(wfb, 1);
@@ -644,6 +660,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_pp_kernel(const GemmParams p
       }
       PP_BAR();
       // phase B
+      PP_JIT();
       PP_READ_X(1);
       if (!hold) {
         PP_ISSUE_WA();
