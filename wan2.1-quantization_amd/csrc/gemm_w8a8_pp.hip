@@ -6,40 +6,38 @@
 // (4002 cycles per K-tile against 2048 of MFMA).  Here the two waves of a SIMD never do the same thing at the same time:
 //
 //   * waves 0-3 (group 0, one per SIMD) and waves 4-7 (group 1, their SIMD partners) run the SAME program one barrier
-//     interval apart (group 1 executes one extra s_barrier in front of a tile, group 0 one behind it).  A K-tile is four
-//     phases per group, each phase = LOAD (<= 12 ds_read_b128 of the next fragments, 2 LDS-DMA pieces, one counted vmcnt
-//     wait) | barrier | BURST (16 back-to-back MFMAs = one quadrant of the wave's 128 x 64 output over the whole 128-deep
-//     K-tile, s_setprio 1) | barrier.  While one wave of a SIMD bursts, its partner loads: the matrix pipe sees one
-//     uninterrupted MFMA stream per slot and the partner's vector-memory / LDS issue never sits in front of an MFMA.
-//   * The LDS-DMA stream is spread evenly: every slot moves one 8-KiB chunk (two 1-KiB pieces per loading wave), issued right
-//     after the chunk's last reader and waited for FIVE load phases of the issuing wave later (s_waitcnt vmcnt(10) at the end of
-//     every load phase, in front of its barrier): ten slots of flight time, nothing is ever drained inside a tile.
-//   * Two 64-KiB K-tile buffers.  Physical row order of a buffer is chosen so that each slot's chunk is what its readers
-//     finished with longest ago:  X rows = tokens in tile order (group g owns rows 128 g .. +127, halves a / b of 64);
+//     interval apart (group 1 executes one extra s_barrier in front of a tile, group 0 one behind it).  A K-tile is TWO
+//     phases per group, each phase = LOAD (16 or 8 ds_read_b128 of the next fragments, 4 LDS-DMA pieces, lgkmcnt(0)) |
+//     barrier | BURST (32 back-to-back MFMAs = half of the wave's 128 x 64 output over the whole 128-deep K-tile,
+//     s_setprio 1, then one counted vmcnt wait) | barrier.  While one wave of a SIMD bursts, its partner loads: the matrix
+//     pipe sees one uninterrupted MFMA stream per slot and the partner's vector-memory / LDS issue never sits in front of an MFMA.
+//   * The LDS-DMA stream is spread and counted, never drained inside a tile (schedule below).
+//   * Two 64-KiB K-tile buffers.  X rows = tokens in tile order (group g owns rows 128 g .. +127, halves a / b of 64);
 //     W rows = [half a of waves 0-3 | half b of waves 0-3], 32 channels each (wave c's channels 64 c + 32 s + r sit at
-//     physical row 128 s + 32 c + r).  Rows are 128 B, 16-B chunk index XORed with (row >> 1) & 7 on the DMA SOURCE address
-//     and on the fragment reads (conflict-free ds_read_b128 for the 16x16x64 operand: gemm_w8a8.hip).
+//     physical row 128 s + 32 c + r), so that a load phase's reads are contiguous sub-tiles.  Rows are 128 B, 16-B chunk
+//     index XORed with (row >> 1) & 7 on the DMA SOURCE address and on the fragment reads (conflict-free ds_read_b128 for
+//     the 16x16x64 operand: gemm_w8a8.hip).
 //   * The issue stream runs two K-tiles ahead of the compute stream and does not know about tile boundaries: the first
 //     K-tiles of the workgroup's NEXT output tile arrive under the last K-tiles of this one.
 //
-// Schedule of one K-tile t (slot numbers relative to group 0's first burst; G0 bursts in even slots, G1 in odd ones):
-//   slot  group  phase  fragment reads               LDS-DMA issued (2 pieces per wave)
-//   -1    G0     L1     X0a(t), Wa(t)    (8 + 4)     X0b(t+1)
-//    0    G1     L1     X1a(t), Wa(t)                X1b(t+1)
-//    1    G0     L2     Wb(t)            (4)         X0a(t+2)
-//    2    G1     L2     Wb(t)                        X1a(t+2)
-//    3    G0     L3     X0b(t)           (8)         Wa rows   0- 63 (t+2)
-//    4    G1     L3     X1b(t)                       Wa rows  64-127 (t+2)
-//    5    G0     L4     --                           Wb rows 128-191 (t+2)
-//    6    G1     L4     --                           Wb rows 192-255 (t+2)
-// Bursts: Q1 = Xa x Wa, Q2 = Xa x Wb, Q3 = Xb x Wb, Q4 = Xb x Wa (64 fragment registers; one operand half is kept from a burst
-// to the next).  Write-after-read: every chunk is re-filled at least two slots (two barriers, and the readers' own
-// lgkmcnt(0)) after its last read.  Read-after-write: a chunk issued in load phase P of a wave is retired by that wave's
-// vmcnt(10) at the end of load phase P + 5 at the latest and first read at least one barrier later (table in DESIGN.md 3.1).
+// Schedule of one K-tile t, WANQ_PP_BURST = 32 (shipped; slots relative to group 0's first burst, G0 bursts in even slots):
+//   slot  group  phase  fragment reads                 LDS-DMA issued (4 pieces per wave)
+//   -1    G0     LA     X0a(t), Wa(t), Wb(t)  (16)     X0a, X0b (t+1)
+//    0    G1     LA     X1a(t), Wa(t), Wb(t)           X1a, X1b (t+1)
+//    1    G0     LB     X0b(t)                (8)      G0's W rows (0-63, 128-191) of (t+2)
+//    2    G1     LB     X1b(t)                         G1's W rows (64-127, 192-255) of (t+2)
+// Bursts QA = Xa x (Wa, Wb), QB = Xb x (Wb, Wa): 64 fragment registers.  Per wave the vector-memory queue reads
+// ... W(t+1) | X(t+1) | W(t+2) | X(t+2) ...; the wait at the END OF A BURST leaves the youngest group in flight and retires the
+// one before it (vmcnt(4)): W(t+1) behind QA(t), X(t+1) behind QB(t) -- 3.5 slots after its issue, one barrier before its first
+// reader (the issuing waves' wait, then the barrier every reader passes).  Write-after-read: W is re-filled ONE slot after its
+// last reader (G1's LA), so load phases finish their reads (lgkmcnt(0)) in front of their barrier; X two slots after.
+// WANQ_PP_BURST = 16 builds the first form (four phases per K-tile, 16-MFMA bursts, one 8-KiB chunk per slot, vmcnt(10) at the
+// end of every load phase: 2775 cycles per K-tile against 2500-2600; kept for the A/B of profiles/r04_l_*, r04_m_*).
 //
-// Epilogue: the v2 kernel's store path (per-wave 4-KiB LDS turn buffers -> whole 128-B lines), with the tile's per-channel
-// values loaded straight into registers (no LDS staging, no workgroup barrier: the ring is full of the next tile's K-tiles).
-// Store instructions share the vmcnt queue with the LDS-DMA pieces, so the first five load phases behind an epilogue wait with
+// Epilogue: the v2 kernel's store path (per-wave 4-KiB LDS turn buffers -> whole 128-B lines); the tile's per-token and
+// per-channel values are prefetched by LDS-DMA into the wave's idle turn buffer two K-tiles ahead (all-fp32 parameter sets;
+// otherwise loaded straight into registers) -- no LDS staging area, no workgroup barrier: the ring is full of the next tile's
+// K-tiles.  Store instructions share the vmcnt queue with the LDS-DMA pieces, so the first burst behind an epilogue waits with
 // the count raised by the stores a FULL tile issues (16 / 32); a ragged tile drains after its store loop instead.  The fp32 +
 // gate + residual epilogue needs 64 KiB for its residual prefetch ring: its kernels do not request the next tile's second
 // K-tile under the last K-tile, use that buffer for the ring and request it behind the store loop.
