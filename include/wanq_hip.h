@@ -297,6 +297,31 @@ int wanq_gemm_w4a8(const int8_t* a, const uint8_t* w_packed, void* out, int out_
 int wanq_lincomb(int n_out, int n_in, const float* coef, const float* const* in, float* const* out, int64_t numel,
                  void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * The fp32 ends of a DiT pass (ViDiT-Q/examples/Wan2.1/wan/modules/model.py:580-610 embeddings, :372-400 Head, :633-656
+ * unpatchify), one fp32 matrix-core tile kernel with the gather / LayerNorm / scatter folded into its loads and stores.
+ * Activations: 0 none, 1 GELU (tanh form), 2 SiLU.  All tensors fp32, row-major, 16-byte aligned; K a multiple of 16.
+ *
+ * wanq_linear_f32:  out[M, N] = act_out(act_in(x)[M, K] . w[N, K]^T + bias)      (bias may be NULL)
+ *   x holds x_rows <= M rows; the missing ones are zeros (text_embedding pads its input to text_len, model.py:600-605).
+ *   replaces nn.Linear / nn.Sequential(Linear, act, Linear) of time_embedding, time_projection, text_embedding.
+ * wanq_time_sinusoid: sinusoidal_embedding_1d (model.py:18-28) of n positions (t_kind: 0 fp32, 1 int64, 2 fp64, 3 int32), float64
+ *   angles, cos half first; out fp32 [n, dim]. */
+int wanq_linear_f32(const float* x, int64_t x_rows, const float* w, const float* bias, float* out, int64_t M, int N, int K,
+                    int in_act, int out_act, void* stream);
+int wanq_time_sinusoid(const void* t, int t_kind, float* out, int n, int dim, void* stream);
+/* wanq_patch_embed: Conv3d(C -> N, kernel = stride = (pt, ph, pw)) on latent [C, F, H, W] (model.py:580-584), w = the
+ *   convolution weight [N, C, pt, ph, pw]; out [out_rows, N], token (f, h, w) in row (f * H/ph + h) * W/pw + w, rows from the token
+ *   count up to out_rows zero (the reference pads the sequence to seq_len, model.py:586-590). */
+int wanq_patch_embed(const float* latent, const float* w, const float* bias, float* out, int C, int F, int H, int W, int pt,
+                     int ph, int pw, int N, int64_t out_rows, void* stream);
+/* wanq_head_fwd: Head.forward (model.py:391-399): LayerNorm(x[rows, K], eps, no affine) * (1 + modulation[1] + e) + modulation[0] + e,
+ *   then Linear(K -> N).  modulation [2, K], e [K].  unpatchify == 0: out [rows, N].  unpatchify != 0: rows must be the token count
+ *   of the latent [C, F, H, W] under patch (pt, ph, pw), N == C * pt * ph * pw <= 64, and out is that latent (model.py:633-656). */
+int wanq_head_fwd(const float* x, const float* modulation, const float* e, const float* w, const float* bias, float* out,
+                  int64_t rows, int K, int N, float eps, int unpatchify, int C, int F, int H, int W, int pt, int ph, int pw,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

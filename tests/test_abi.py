@@ -64,7 +64,7 @@ def test_round2_entry_points_refuse_bad_arguments(lib):
     i64 = ctypes.c_int64
     buf = ctypes.create_string_buffer(256)
     p = ctypes.cast(buf, ctypes.c_void_p)
-    assert lib.wanq_abi_version() == 4
+    assert lib.wanq_abi_version() == 5
     # W4A8: K must hold whole 32-code groups
     rc = lib.wanq_gemm_w4a8(p, p, p, 0, p, None, 0, p, None, 0, None, 0, None, None, 0, i64(8), 16, 48, None)
     assert rc == 2 and b"K=48" in lib.wanq_last_error()

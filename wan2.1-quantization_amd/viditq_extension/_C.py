@@ -26,7 +26,7 @@ lib = ctypes.CDLL(LIB_PATH)
 
 F16, BF16, F32, I32, I16 = 0, 1, 2, 3, 4
 EPI_GELU, EPI_GATE_RES = 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
@@ -39,6 +39,10 @@ PROTOTYPES = {
     "wanq_gemm_w4a8": [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i64, _i, _i, _vp],
     "wanq_gemm_select_kernel": [_i],
     "wanq_lincomb": [_i, _i, _vp, _vp, _vp, _i64, _vp],
+    "wanq_linear_f32": [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp],
+    "wanq_time_sinusoid": [_vp, _i, _vp, _i, _i, _vp],
+    "wanq_patch_embed": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _vp],
+    "wanq_head_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "wanq_col_absmax": [_vp, _i, _vp, _i64, _i, _vp],
     "wanq_row_minmax": [_vp, _i, _vp, _vp, _vp, _i64, _i, _vp],
     "wanq_weight_quant": [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _i64, _i, _vp],

@@ -287,3 +287,92 @@ def attention(q, k, v, num_heads, k_len=None, out=None, splits=None):
             ev1.record()
             _attn_timer.append((ev0, ev1, 4 * Lq * Lk * d * num_heads))
     return out
+
+
+# ---------------------------------------------------------------- the fp32 ends of a DiT pass (csrc/embed_head.hip)
+_ACT = {None: 0, "gelu_tanh": 1, "silu": 2}
+_T_KIND = {torch.float32: 0, torch.int64: 1, torch.float64: 2, torch.int32: 3}
+
+
+def _f32(name, t, *shape):
+    _C.check_gpu(name, t)
+    _C.check_dtype(name, t, torch.float32)
+    _C.check_contig(name, t)
+    if shape:
+        _C.check_shape(name, t, *shape)
+    return t
+
+
+def linear_f32(x, weight, bias=None, in_act=None, out_act=None, rows=None):
+    """act_out(act_in(x) @ weight.T + bias) in fp32 on the matrix cores; x [x_rows, K], weight [N, K].  rows > x_rows computes the
+    missing input rows as zeros (text_embedding's padding to text_len, reference model.py:600-605)."""
+    _f32("x", x)
+    _f32("weight", weight)
+    if x.dim() != 2 or weight.dim() != 2 or x.shape[1] != weight.shape[1]:
+        raise RuntimeError(f"linear_f32: x {tuple(x.shape)} against weight {tuple(weight.shape)}")
+    n, k = weight.shape
+    if bias is not None:
+        _f32("bias", bias, n)
+    rows = x.shape[0] if rows is None else int(rows)
+    out = torch.empty(rows, n, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _C.call("wanq_linear_f32", _C.ptr(x), x.shape[0], _C.ptr(weight), _C.ptr(bias), _C.ptr(out), rows, n, k, _ACT[in_act],
+                _ACT[out_act], _C.stream())
+    return out
+
+
+def time_sinusoid(t, dim):
+    """sinusoidal_embedding_1d(dim, t).float() (reference model.py:18-28; float64 angles on the device) -> fp32 [len(t), dim]."""
+    _C.check_gpu("t", t)
+    _C.check_contig("t", t)
+    t = t.reshape(-1)
+    if t.dtype not in _T_KIND:
+        t = t.to(torch.float64)
+    out = torch.empty(t.numel(), dim, dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        _C.call("wanq_time_sinusoid", _C.ptr(t), _T_KIND[t.dtype], _C.ptr(out), t.numel(), dim, _C.stream())
+    return out
+
+
+def patch_embed(latent, weight, bias, out_rows=None):
+    """Conv3d(kernel == stride) patch embedding of latent [C, F, H, W] with the convolution's own weight [N, C, pt, ph, pw]:
+    -> ([out_rows, N] tokens in (f, h, w) order, rows past the token count zero; the token grid)."""
+    _f32("latent", latent)
+    _f32("weight", weight)
+    if latent.dim() != 4 or weight.dim() != 5 or weight.shape[1] != latent.shape[0]:
+        raise RuntimeError(f"patch_embed: latent {tuple(latent.shape)} against weight {tuple(weight.shape)}")
+    c, f, h, w = latent.shape
+    n, _, pt, ph, pw = weight.shape
+    if bias is not None:
+        _f32("bias", bias, n)
+    grid = (f // pt, h // ph, w // pw)
+    tokens = grid[0] * grid[1] * grid[2]
+    out_rows = tokens if out_rows is None else int(out_rows)
+    out = torch.empty(out_rows, n, dtype=torch.float32, device=latent.device)
+    with torch.cuda.device(latent.device):
+        _C.call("wanq_patch_embed", _C.ptr(latent), _C.ptr(weight), _C.ptr(bias), _C.ptr(out), c, f, h, w, pt, ph, pw, n, out_rows,
+                _C.stream())
+    return out, grid
+
+
+def head(x, modulation, e, weight, bias, eps, latent_shape=None, patch=None):
+    """Head.forward (reference model.py:391-399) on x [rows, K]: LayerNorm * (1 + modulation[1] + e) + modulation[0] + e, Linear.
+    latent_shape = (C_out, F, H, W) with patch = (pt, ph, pw) also unpatchifies (model.py:633-656) and returns that latent;
+    otherwise [rows, N]."""
+    _f32("x", x)
+    rows, k = x.shape
+    _f32("modulation", modulation, 2, k)
+    _f32("e", e, k)
+    _f32("weight", weight)
+    n = weight.shape[0]
+    _C.check_shape("weight", weight, n, k)
+    if bias is not None:
+        _f32("bias", bias, n)
+    if latent_shape is None:
+        out, geo, un = torch.empty(rows, n, dtype=torch.float32, device=x.device), (0,) * 7, 0
+    else:
+        out, geo, un = torch.empty(*latent_shape, dtype=torch.float32, device=x.device), (*latent_shape, *patch), 1
+    with torch.cuda.device(x.device):
+        _C.call("wanq_head_fwd", _C.ptr(x), _C.ptr(modulation), _C.ptr(e), _C.ptr(weight), _C.ptr(bias), _C.ptr(out), rows, k, n,
+                float(eps), un, *[int(g) for g in geo], _C.stream())
+    return out

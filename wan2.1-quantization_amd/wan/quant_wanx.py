@@ -6,6 +6,7 @@ Counterpart of ViDiT-Q/examples/Wan2.1/wan/quant_wanx.py:28-228 (same method nam
 Simulation mode = the qdiff drop-in layers inside the unmodified WanAttentionBlock (they already compute in int8);
 kernel mode = every block replaced by WanAttentionBlockWithHipKernel (fused producers / epilogues around the GEMMs)."""
 import logging
+import math
 
 import torch
 import torch.nn as nn
@@ -193,19 +194,20 @@ class QuantWanModel(WanModel, QuantModel):
             self._rope_cache[grid] = ops.rope_table(self.freqs, grid, device)
         return self._rope_cache[grid]
 
-    def _context_source(self, raw, embedded):
-        """The blocks' view of one text context, with what they derive from it kept across the sampling loop.  Everything a block
-        computes from the context alone -- its plain int8 copy, cross_attn.k (+ RMSNorm) and cross_attn.v -- is independent of
-        the timestep and the latent, and text2video.py hands every step the SAME context tensors (cond, uncond), so it is kept
-        per live tensor: the entry holds the tensor itself (its storage cannot be recycled under the cache) and its in-place
-        version counter; a different tensor, or the same one after an in-place write, recomputes.  At most four entries;
-        `context_cache = False` (bench.py --no-context-cache) turns it off, anything that rebuilds the kernel-mode blocks
-        (hardware_forward_refactor, shard_blocks) empties it.  Never used under graph capture (wan/graph.py turns it off for its
-        warm-up and capture as well): a captured graph must hold the cross_attn.k / .v launches itself -- it would otherwise bake in
-        pointers to tensors that only this cache owns (freed by the fifth other context or a rebuild of the blocks) and ignore
-        later in-place updates of its static context buffers."""
-        src = lambda: _FpSrc(embedded.float().contiguous(), self.hip_blocks[0].act_dtype)  # noqa: E731
-        if not getattr(self, "context_cache", True) or (embedded.is_cuda and torch.cuda.is_current_stream_capturing()):
+    def _context_source(self, raw, embed):
+        """The blocks' view of one text context, with what they derive from it kept across the sampling loop.  Everything a pass
+        computes from the context alone -- text_embedding, its plain int8 copy, cross_attn.k (+ RMSNorm) and cross_attn.v -- is
+        independent of the timestep and the latent, and text2video.py hands every step the SAME context tensors (cond, uncond), so
+        it is kept per live tensor: the entry holds the tensor itself (its storage cannot be recycled under the cache) and its
+        in-place version counter; a different tensor, or the same one after an in-place write, recomputes.  `embed` is the callable
+        that runs text_embedding (only on a miss).  At most four entries; `context_cache = False` (bench.py --no-context-cache)
+        turns it off, anything that rebuilds the kernel-mode blocks (hardware_forward_refactor, shard_blocks) empties it.  Never
+        used under graph capture (wan/graph.py turns it off for its warm-up and capture as well): a captured graph must hold the
+        text_embedding / cross_attn.k / .v launches itself -- it would otherwise bake in pointers to tensors that only this cache
+        owns (freed by the fifth other context or a rebuild of the blocks) and ignore later in-place updates of its static
+        context buffers."""
+        src = lambda: _FpSrc(embed().float().contiguous(), self.hip_blocks[0].act_dtype)  # noqa: E731
+        if not getattr(self, "context_cache", True) or (raw.is_cuda and torch.cuda.is_current_stream_capturing()):
             return src()
         cache = self.__dict__.setdefault("_ctx_cache", [])
         for ent in cache:
@@ -217,30 +219,52 @@ class QuantWanModel(WanModel, QuantModel):
         del cache[:-4]
         return cq
 
+    def _embed_hip(self, xi, ti, seq_len):
+        """The embeddings in front of the blocks (reference model.py:580-597) on csrc/embed_head.hip, all fp32: patch embedding
+        gathered straight from the latent (padded to seq_len rows with zeros), sinusoid -> time_embedding -> time_projection.
+        -> (h [seq_len, dim], e [dim], e0 [1, 6, dim], token grid)."""
+        pe, te, tp = self.patch_embedding, self.time_embedding, self.time_projection
+        dev = pe.weight.device
+        h, grid = ops.patch_embed(xi.to(dev, torch.float32).contiguous(), pe.weight, pe.bias, out_rows=seq_len)
+        assert math.prod(grid) <= seq_len
+        e = ops.linear_f32(ops.time_sinusoid(ti.to(dev), self.freq_dim), te[0].weight, te[0].bias, out_act="silu")
+        e = ops.linear_f32(e, te[2].weight, te[2].bias)
+        e0 = ops.linear_f32(e, tp[1].weight, tp[1].bias, in_act="silu")
+        return h, e[0], e0.view(1, 6, self.dim), grid
+
+    def _text_embed_hip(self, ci):
+        """text_embedding (reference model.py:600-605): the context padded to text_len rows with zeros BEFORE the MLP."""
+        tx = self.text_embedding
+        c = ci.to(tx[0].weight.device, torch.float32).contiguous()
+        assert c.shape[0] <= self.text_len
+        return ops.linear_f32(ops.linear_f32(c, tx[0].weight, tx[0].bias, out_act="gelu_tanh", rows=self.text_len), tx[2].weight, tx[2].bias)
+
     @torch.no_grad()
     def forward(self, x, t, context, seq_len, sp=None):
         if self.hip_blocks is None:  # simulation mode: the fake-quant Linears are token-local, the FP model's Ulysses path applies
             return WanModel.forward(self, x, t, context, seq_len, sp)
         outs = []
+        hd = self.head
         for xi, ci, ti in zip(x, context, t.reshape(-1, 1)):
             with torch.autocast("cuda", enabled=False):
-                h, e, e0, ctx, seq_lens, grids = self.embed([xi], ti, [ci], seq_len)
-                h = h[0].float()
-                rope = self._rope(grids[0], h.device)
+                h, e, e0, grid = self._embed_hip(xi, ti, seq_len)
+                L0 = math.prod(grid)
+                rope = self._rope(grid, h.device)
                 if sp is not None and sp.size > 1:
                     lp = seq_len // sp.size
-                    h = sp.shard_rows(h)
+                    h = sp.shard_rows(h).contiguous()
                     rope = rope[sp.rank * lp:(sp.rank + 1) * lp]
-                h = h.contiguous()
-                cq = self._context_source(ci, ctx[0])
+                cq = self._context_source(ci, lambda: self._text_embed_hip(ci))
                 if getattr(self, "_fsdp", None) is not None:
-                    e0f, L0 = e0.float(), seq_lens[0]
-                    self._fsdp.run(lambda blk: blk(h, e0f, rope, L0, cq, sp))
+                    self._fsdp.run(lambda blk: blk(h, e0, rope, L0, cq, sp))
                 else:
                     for blk in self.hip_blocks:
-                        blk(h, e0.float(), rope, seq_lens[0], cq, sp)
-                out = self.head(h.unsqueeze(0), e)
-                if sp is not None and sp.size > 1:
-                    out = sp.all_gather_rows(out[0]).unsqueeze(0)
-                outs.append(self.unpatchify(out, grids)[0].float())
+                        blk(h, e0, rope, L0, cq, sp)
+                hw, hb, mod = hd.head.weight, hd.head.bias, hd.modulation.view(2, self.dim)
+                if sp is not None and sp.size > 1:  # the head is token-local: on the shard, then gathered (xdit_context_parallel.py:138-142)
+                    out = sp.all_gather_rows(ops.head(h, mod, e, hw, hb, hd.eps)).unsqueeze(0)
+                    outs.append(self.unpatchify(out, [grid])[0].float())
+                else:  # LayerNorm + modulation + Linear + unpatchify in one launch
+                    latent = (self.out_dim, *[g * p for g, p in zip(grid, self.patch_size)])
+                    outs.append(ops.head(h[:L0], mod, e, hw, hb, hd.eps, latent_shape=latent, patch=self.patch_size))
         return outs
