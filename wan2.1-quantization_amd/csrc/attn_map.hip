@@ -222,6 +222,9 @@ __global__ __launch_bounds__(512, PASS == 2 ? 2 : 4) void attn_map_kernel(const 
   __builtin_amdgcn_s_barrier();
 
   if (PASS == 0) {
+    // the column maxima pass 1 accumulates by atomic max start from zero: cleared here (one launch fewer than a memset)
+    if (blockIdx.x == 0)
+      for (int i = tid; i < p.Lk; i += 512) p.cmax[(int64_t)head * p.Lk + i] = 0.f;
     // lane-local online statistics over the keys this lane sees (a query's four lanes n, n+16, n+32, n+48 see different keys);
     // merged across the four lanes at the end
     float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
@@ -431,12 +434,8 @@ static int launch_attn_map(const AttnMapParams& p, hipStream_t st, const char* w
     attr_done = true;
   }
   const int64_t nk = (int64_t)p.Lk * p.H;
-  if (hipMemsetAsync(p.cmax, 0, (size_t)nk * sizeof(float), st) != hipSuccess) {
-    set_error("%s: hipMemsetAsync failed", what);
-    return WANQ_E_LAUNCH;
-  }
   const dim3 grid((unsigned)((p.Lq + 255) / 256), (unsigned)p.H);  // 8 waves x 32 queries
-  hipLaunchKernelGGL((attn_map_kernel<0, QK8>), grid, dim3(512), lds0, st, p);
+  hipLaunchKernelGGL((attn_map_kernel<0, QK8>), grid, dim3(512), lds0, st, p);  // also clears cmax
   hipLaunchKernelGGL((attn_map_kernel<1, QK8>), grid, dim3(512), lds1, st, p);
   hipLaunchKernelGGL(attn_map_delta_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, p.cmax, p.delta, nk, p.levels, p.eps);
   hipLaunchKernelGGL((attn_map_kernel<2, QK8>), grid, dim3(512), lds2, st, p);

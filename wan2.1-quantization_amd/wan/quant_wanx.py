@@ -173,6 +173,9 @@ class QuantWanModel(WanModel, QuantModel):
                         taken += 1
                     lin.refresh_zp_gemm()
             logger.info("loaded %d tensors of the integer checkpoint %s into the kernel-mode blocks", taken, load_path)
+        for i, hb in enumerate(self.hip_blocks):
+            hb.block_index = i
+        self.__dict__.pop("_mod_all", None)
         return self
 
     def shard_blocks(self, group=None):
@@ -219,6 +222,16 @@ class QuantWanModel(WanModel, QuantModel):
         del cache[:-4]
         return cq
 
+    def _modulations(self, device):
+        """All kernel-mode blocks' modulation tables as one [blocks, 6, C] tensor (so that `modulation + e0` of reference
+        model.py:322-324 is one launch per pass, not one per block); rebuilt when a block's table was written or moved."""
+        key = (device, tuple(hb.modulation._version for hb in self.hip_blocks), tuple(hb.modulation.data_ptr() for hb in self.hip_blocks))
+        ent = self.__dict__.get("_mod_all")
+        if ent is None or ent[0] != key:
+            ent = (key, torch.cat([hb.modulation.to(device) for hb in self.hip_blocks]).contiguous())
+            self.__dict__["_mod_all"] = ent
+        return ent[1]
+
     def _embed_hip(self, xi, ti, seq_len):
         """The embeddings in front of the blocks (reference model.py:580-597) on csrc/embed_head.hip, all fp32: patch embedding
         gathered straight from the latent (padded to seq_len rows with zeros), sinusoid -> time_embedding -> time_projection.
@@ -255,11 +268,12 @@ class QuantWanModel(WanModel, QuantModel):
                     h = sp.shard_rows(h).contiguous()
                     rope = rope[sp.rank * lp:(sp.rank + 1) * lp]
                 cq = self._context_source(ci, lambda: self._text_embed_hip(ci))
+                e_all = self._modulations(e0.device) + e0  # every block's modulation + e0 (reference model.py:322-324), one launch per pass
                 if getattr(self, "_fsdp", None) is not None:
-                    self._fsdp.run(lambda blk: blk(h, e0, rope, L0, cq, sp))
+                    self._fsdp.run(lambda blk: blk(h, e0, rope, L0, cq, sp, e=e_all[blk.block_index:blk.block_index + 1]))
                 else:
-                    for blk in self.hip_blocks:
-                        blk(h, e0, rope, L0, cq, sp)
+                    for i, blk in enumerate(self.hip_blocks):
+                        blk(h, e0, rope, L0, cq, sp, e=e_all[i:i + 1])
                 hw, hb, mod = hd.head.weight, hd.head.bias, hd.modulation.view(2, self.dim)
                 if sp is not None and sp.size > 1:  # the head is token-local: on the shard, then gathered (xdit_context_parallel.py:138-142)
                     out = sp.all_gather_rows(ops.head(h, mod, e, hw, hb, hd.eps)).unsqueeze(0)

@@ -399,13 +399,15 @@ class WanAttentionBlockWithHipKernel(nn.Module):
             b.wait()
         return o
 
-    def forward(self, x, e0, rope, seq_len, ctx, sp=None):
+    def forward(self, x, e0, rope, seq_len, ctx, sp=None, e=None):
         """x: fp32 [L, C] residual stream (this rank's token shard under sequence parallelism), updated IN PLACE.
         e0: fp32 [1, 6, C].  rope: fp32 [pos, d/2, 2] for the local tokens.  seq_len: number of real (unpadded)
         tokens of the WHOLE sequence.  ctx: _FpSrc of the bf16 text context [Lc, C] (shared by all blocks so that
-        its plain int8 copy is made once per pass).  sp: wan.distributed.SeqParallel or None."""
+        its plain int8 copy is made once per pass).  sp: wan.distributed.SeqParallel or None.  e: this block's
+        `modulation + e0` when the caller has it already (the model adds all blocks' modulations in one launch per pass)."""
         H, d = self.num_heads, self.head_dim
-        e = self.modulation + e0  # [1, 6, C] fp32
+        if e is None:
+            e = self.modulation + e0  # [1, 6, C] fp32
         sa, ca = self.self_attn, self.cross_attn
 
         # ---- self attention: LN*(1+e1)+e0 -> q,k,v -> RMSNorm+RoPE -> attention -> o (+gate, +residual)
