@@ -34,6 +34,7 @@ def sequence(plain):
         vv = v.clone()
         o = ops.attention(q, k, vv, H, L) if plain else ops.attention_map_quant(q, k, vv, H, 8, False, L, q_len=L)
         return q, k, o
+    run.q_raw, run.rope = q_raw.float().cpu(), rope.cpu()
     return run
 
 
@@ -84,6 +85,17 @@ def main():
                 if first is None and not torch.equal(q, q0):
                     dd = (q.view(torch.int16) != q0.view(torch.int16)).nonzero()
                     first = (dd[:, 0].unique().tolist(), dd[:, 1].tolist()[:24])
+                    if "--rope-only" in sys.argv:  # what IS the wrong value?  candidates: the inputs a, b of the pair, the table's cos / sin
+                        r0 = int(dd[0, 0])
+                        rows = []
+                        for c in dd[dd[:, 0] == r0][:, 1].tolist()[:6]:
+                            pr = (c % 128) // 2
+                            a_, b_ = att.q_raw[r0, c & ~1].item(), att.q_raw[r0, c | 1].item()
+                            cs_, sn_ = att.rope[r0, pr, 0].item(), att.rope[r0, pr, 1].item()
+                            rows.append(f"col {c}: got {q[r0, c].item():.4f} want {q0[r0, c].item():.4f} | a {a_:.4f} b {b_:.4f} cos {cs_:.4f} sin {sn_:.4f} "
+                                        f"a*cos {a_ * cs_:.4f} b*sin {b_ * sn_:.4f} a*sin {a_ * sn_:.4f} b*cos {b_ * cs_:.4f} | table row +0..3 of the lane: "
+                                        f"{[round(x, 4) for x in att.rope[r0].flatten()[(c % 128) // 8 * 8:(c % 128) // 8 * 8 + 8].tolist()]}")
+                        first = (first, rows)
             del junk
         print(f"one process, attention_map_quant on a side stream beside {'attention' if plain else 'attention_map_quant'} "
               f"[{' '.join(a for a in sys.argv[2:])}]: {10 * n} sequences, mismatches {bad}; first q: {first}", flush=True)
