@@ -1,6 +1,6 @@
 """Kernels of this library running BESIDE each other (another stream) must not change each other's results.  Regression test of
 profiles/r04_z_corun_corruption.txt: with the attention-map passes on a side stream, RMSNorm+RoPE on the main stream returned one
-wrong element per 16-byte chunk in the last 16 lanes of a row in ~0.4 % of launches (a load beat landing behind a counted wait)."""
+wrong element per 16-byte chunk in the last 16 lanes of a row in ~0.4 % of launches (a packed multiply reading 0 while the wave's other load was returning)."""
 import os
 import sys
 

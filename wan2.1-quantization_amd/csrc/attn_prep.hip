@@ -93,11 +93,12 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const PrepParams p) {
       const int pair0 = (c0 % p.head_dim) >> 1;  // 4 consecutive complex pairs of one head
       float cs[8];
       Io<F32>::load8(p.rope, (pos * half + pair0) * 2, cs);
-      // BOTH 16-byte pieces of the table row have landed before either is used.  hipcc otherwise waits for the first piece only
-      // (s_waitcnt vmcnt(1)); with the attention-map kernels running beside this kernel (another stream or another process on
-      // the GPU) the last 16-lane beat of that piece arrived AFTER the counted wait in ~0.4 % of launches: a sin register still
-      // read 0 in lanes 48-63 and one element per 16-byte chunk came out as a*cos instead of a*cos - b*sin
-      // (tools/probes/attn_map_coherence.py, profiles/r04_z_corun_corruption.txt; 0 of 30000 with this wait).
+      // BOTH 16-byte pieces of the table row have landed before the first packed fp32 op.  hipcc otherwise waits for the first
+      // piece only (s_waitcnt vmcnt(1)); with the attention-map kernels running beside this kernel (another stream or another
+      // process on the GPU) a v_pk_mul_f32 reading the high register of a source pair through op_sel then returned 0 for lanes
+      // 48-63 in ~0.4 % of launches while the second piece was still returning: one element per 16-byte chunk came out as a*cos
+      // instead of a*cos - b*sin (profiles/r04_z_corun_corruption.txt; micro-victim tools/probes/late_beat.py; 0 of 30000 with
+      // this wait).
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(cs[0]), "+v"(cs[1]), "+v"(cs[2]), "+v"(cs[3]), "+v"(cs[4]), "+v"(cs[5]), "+v"(cs[6]), "+v"(cs[7]));
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
