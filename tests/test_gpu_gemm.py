@@ -233,6 +233,36 @@ def test_w4a8_epilogue_matches_w8a8_on_unpacked_codes():
         assert torch.allclose(y4.float(), y8.float(), rtol=tol, atol=tol * float(y8.float().abs().max())), (y4.float() - y8.float()).abs().max()
 
 
+@pytest.mark.parametrize("M,N,K,kw", [(4096, 1536, 8960, dict(out_dtype=torch.bfloat16, gelu=True)),
+                                      (9450, 1024, 13824, dict(out_dtype=torch.float32, gate=True)),
+                                      (2048, 520, 512, dict(out_dtype=torch.float16)), (33000, 264, 256, dict(out_dtype=torch.bfloat16))])
+def test_w4a8_expanded_once_at_large_m_is_bit_equal_to_the_in_kernel_expansion(M, N, K, kw):
+    """From WANQ_W4_UNPACK_ROWS rows on, w8a8_linear(w4=True) expands the packed weights once per launch and runs the W8 ping-pong
+    kernel; the in-register expansion of wanq_gemm_w4a8 (forced by a threshold of 0) gives the same bits."""
+    mod = qgemm()
+    rng = np.random.default_rng(M + N)
+    a = t(rng.integers(-127, 128, size=(M, K), dtype=np.int8))
+    q = rng.integers(-8, 8, size=(N, K), dtype=np.int8)
+    sa, sw = t(rng.uniform(0.005, 0.02, M).astype(np.float32)), t(rng.uniform(0.01, 0.03, N).astype(np.float32))
+    asum = (a.float().sum(1) * sa).contiguous()
+    zp = t(rng.integers(0, 16, N).astype(np.float32)) - 8.0
+    bias = t(rng.normal(size=N).astype(np.float32))
+    kw = dict(kw)
+    if kw.pop("gate", False):
+        kw.update(gate=t(rng.normal(size=N).astype(np.float32)), residual=t(rng.normal(size=(M, N)).astype(np.float32)))
+    packed = mod.pack_w4(t(q), bias=8)
+    keep = mod._W4_UNPACK_ROWS
+    try:
+        mod._W4_UNPACK_ROWS = 2048
+        y_once = mod.w8a8_linear(a, packed, sa, sw, bias, asum, zp, w4=True, **kw)
+        mod._W4_UNPACK_ROWS = 0
+        y_tile = mod.w8a8_linear(a, packed, sa, sw, bias, asum, zp, w4=True, **kw)
+    finally:
+        mod._W4_UNPACK_ROWS = keep
+    assert torch.equal(y_once, y_tile)
+    assert torch.equal(packed, mod.pack_w4(t(q), bias=8))  # the weights at rest are untouched
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # The ping-pong persistent kernel (csrc/gemm_w8a8_pp.hip) against the other two kernels in ONE process
 # (wanq_gemm_select_kernel): same accumulators; the two persistent kernels share the epilogue expression -> bit-identical.

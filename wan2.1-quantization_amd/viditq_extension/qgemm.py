@@ -6,6 +6,8 @@ C assert that aborts the process otherwise); per-token / per-channel vectors fp1
 int16 or fp32; output fp16 (reference), bf16 or fp32; launched on the CURRENT stream (reference: legacy
 default stream).
 """
+import os
+
 import torch
 
 from . import _C
@@ -41,12 +43,22 @@ def _check_vec(name, t, n, dtypes=_VEC):
     _C.check_shape(name, t, n)
 
 
+# Packed 4-bit weights at large M: the int8 matrix cores are the bound, not the weight bytes, so the fastest W4A8 product on this
+# machine is the W8 ping-pong kernel on codes expanded ONCE per launch (wanq_unpack_w4: 1.5 N K bytes of traffic, 1-6 % of the
+# product's time from 32760 down to 9450 rows) instead of once per tile inside the kernel (wanq_gemm_w4a8's in-register expansion
+# costs ~20 % there).  The nibbles u = q + 8 go in as they are: the 8 rides in the zero point both ways (include/wanq_hip.h), the
+# int32 accumulators and the epilogue are the same, outputs bit-equal (tests/test_gpu_gemm.py).  Weights stay packed at rest; the
+# expanded copy lives for the launch.  WANQ_W4_UNPACK_ROWS: minimum M (0 = never).
+_W4_UNPACK_ROWS = int(os.environ.get("WANQ_W4_UNPACK_ROWS", "2048"))
+
+
 def w8a8_linear(input, weight, scale_input, scale_weight, bias=None, input_sum=None, zp_weight=None,
                 out_dtype=torch.float16, gelu=False, gate=None, residual=None, out=None, w4=False):
     """General entry: y = epilogue(int8 input[M,K] @ int8 weight[N,K]^T); see include/wanq_hip.h.
 
     gate (fp32 [N]) + residual ([M,N], out dtype): y = residual + y * gate (may alias `out`).
-    w4=True: `weight` is uint8 [N, K/2], unsigned 4-bit codes in the pack_w4 layout (wanq_gemm_w4a8)."""
+    w4=True: `weight` is uint8 [N, K/2], unsigned 4-bit codes in the pack_w4 layout (wanq_gemm_w4a8; at M >= WANQ_W4_UNPACK_ROWS and
+    K % 128 == 0 expanded once and multiplied by the W8 ping-pong kernel, see _W4_UNPACK_ROWS)."""
     _check_i8("input", input)
     M, K = input.shape
     if w4:
@@ -94,6 +106,8 @@ def w8a8_linear(input, weight, scale_input, scale_weight, bias=None, input_sum=N
         if _timer is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
+        if w4 and _W4_UNPACK_ROWS and M >= _W4_UNPACK_ROWS and K % 128 == 0 and K >= 256:
+            weight, w4 = unpack_w4(weight, bias=0), False  # inside the timed region: part of this product's cost
         _C.call("wanq_gemm_w4a8" if w4 else "wanq_gemm_w8a8", _C.ptr(input), _C.ptr(weight), _C.ptr(out), _C.dt(out_dtype), _C.ptr(scale_input),
                 _C.ptr(input_sum), _C.dt(scale_input), _C.ptr(scale_weight), _C.ptr(bias), _C.dt(scale_weight),
                 _C.ptr(zp_weight), _C.dt(zp_weight) if zp_weight is not None else _C.F32, _C.ptr(gate),
