@@ -40,7 +40,7 @@ def main():
              11: "as 10, two plain v_mul_f32 in place of the second packed multiply",
              9: "as 4 + a plain v_mov of A's last register right behind the multiply, returned as 'A.x' (dword 0)"}
     for beside in (False, True):
-        for mode in ((10, 11) if "--pk3" in sys.argv else (8, 9) if "--pk2" in sys.argv else (4, 5, 6, 7) if "--pk" in sys.argv else (0, 1, 2, 3, 4)):
+        for mode in ((4,) if "--pk0" in sys.argv else (10, 11) if "--pk3" in sys.argv else (8, 9) if "--pk2" in sys.argv else (4, 5, 6, 7) if "--pk" in sys.argv else (0, 1, 2, 3, 4)):
             early = torch.empty(per, rows, 64, 8, device="cuda")
             second = torch.empty(per, rows, 64, 4, device="cuda")
             where, vals, launches, bad_launches, bad_second = collections.Counter(), collections.Counter(), 0, 0, 0
