@@ -242,11 +242,28 @@ __device__ __forceinline__ void read_lane_scales(const GemmParams& p, LaneScales
 
 // (GELU is a template parameter of the store loops: tested per call site, the flag put a branch behind every four values --
 // 32 per tile -- and no two groups' conversion chains overlapped)
-template <bool GELU>
+// PK: the same expression on channel PAIRS (v_pk_mul_f32 / v_pk_fma_f32: IEEE per half, bit-identical to the scalar form, 2.25
+// instead of 4 vector instructions per value).  Used by the 16-bit and plain 32-bit store loops (bf16 q / k / v GEMM 1.050x, GELU
+// ffn.0 1.048x, 14B shapes 1.02x alone); the gate + residual loop keeps the scalar form, which the packed one slowed to 0.953x at
+// K = 1536 (profiles/r04_zz_gemm_pk_epilogue_ab.txt).
+template <bool GELU, bool PK>
 __device__ __forceinline__ void dequant4(const v4i& a, const LaneScales& s, int i, int j, float (&y)[4]) {
+  if (PK) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f sa2 = {s.sa[j], s.sa[j]}, as2 = {s.asum[j], s.asum[j]};
 #pragma unroll
-  for (int e = 0; e < 4; ++e)  // acc*sA*sW + (sumA*(zp*sW) + bias): the v2 kernel's expression, bit for bit
-    y[e] = fmaf((float)a[e] * s.sa[j], s.sw[i][e], fmaf(s.asum[j], s.zs[i][e], s.b[i][e]));
+    for (int h = 0; h < 2; ++h) {
+      const v2f af = {(float)a[2 * h], (float)a[2 * h + 1]};
+      const v2f sw2 = {s.sw[i][2 * h], s.sw[i][2 * h + 1]}, zs2 = {s.zs[i][2 * h], s.zs[i][2 * h + 1]}, b2 = {s.b[i][2 * h], s.b[i][2 * h + 1]};
+      const v2f r = __builtin_elementwise_fma(af * sa2, sw2, __builtin_elementwise_fma(as2, zs2, b2));
+      y[2 * h] = r.x;
+      y[2 * h + 1] = r.y;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)  // acc*sA*sW + (sumA*(zp*sW) + bias): the v2 kernel's expression, bit for bit
+      y[e] = fmaf((float)a[e] * s.sa[j], s.sw[i][e], fmaf(s.asum[j], s.zs[i][e], s.b[i][e]));
+  }
   if (GELU) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_fast_f32(y[e]);
@@ -266,7 +283,7 @@ __device__ __forceinline__ void store16(const GemmParams& p, v4i (&acc)[4][8], c
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float y[4];
-        dequant4<GELU>(acc[i][j], s, i, j, y);
+        dequant4<GELU, true>(acc[i][j], s, i, j, y);
         const int cb = (i * 16 + 4 * eq4) * 2;  // byte column inside the 128-B row
         *reinterpret_cast<uint2*>(tb + tr * 128 + ((((cb >> 4) ^ (tr & 7)) << 4) | (cb & 15))) = pack16x4<OUT>(y);
       }
@@ -306,7 +323,7 @@ __device__ __forceinline__ void store32(const GemmParams& p, v4i (&acc)[4][8], c
             *reinterpret_cast<int4*>(dst) = make_int4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
           } else {
             float y[4];
-            dequant4<GELU>(acc[i][j], s, i, j, y);
+            dequant4<GELU, true>(acc[i][j], s, i, j, y);
             *reinterpret_cast<float4*>(dst) = make_float4(y[0], y[1], y[2], y[3]);
           }
         }
@@ -355,7 +372,7 @@ __device__ __forceinline__ void store32_res(const GemmParams& p, v4i (&acc)[4][8
       for (int ii = 0; ii < 2; ++ii) {
         const int i = 2 * ih + ii;
         float y[4];
-        dequant4<GELU>(acc[i][j], s, i, j, y);
+        dequant4<GELU, false>(acc[i][j], s, i, j, y);
         *reinterpret_cast<float4*>(tb + tr * 128 + (((4 * ii + eq4) ^ (tr & 7)) << 4)) = make_float4(y[0], y[1], y[2], y[3]);
       }
     }
