@@ -102,9 +102,11 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const PrepParams p) {
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(cs[0]), "+v"(cs[1]), "+v"(cs[2]), "+v"(cs[3]), "+v"(cs[4]), "+v"(cs[5]), "+v"(cs[6]), "+v"(cs[7]));
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
+        // roundings fixed in the source (a product, then one fused multiply-add), so that every instantiation of this kernel and
+        // every compiler mood gives the same bits: left to -ffp-contract the plain and the int8 form once disagreed
         const float a = v[i][2 * k], b = v[i][2 * k + 1];
-        v[i][2 * k] = a * cs[2 * k] - b * cs[2 * k + 1];
-        v[i][2 * k + 1] = a * cs[2 * k + 1] + b * cs[2 * k];
+        v[i][2 * k] = fmaf(a, cs[2 * k], -__fmul_rn(b, cs[2 * k + 1]));
+        v[i][2 * k + 1] = fmaf(a, cs[2 * k + 1], __fmul_rn(b, cs[2 * k]));
       }
     }
     if (SC) {

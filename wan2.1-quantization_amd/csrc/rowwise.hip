@@ -444,11 +444,28 @@ __global__ __launch_bounds__(256, 2) void quant_rows_wave_kernel(const void* x, 
   for (int i = 0; i < NCH; ++i) {
     const bool ok = 2 * (lane + 64 * (i >> 1)) + (i & 1) <= last;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float t = GELU ? gelu_tanh_fast_f32(v[i][j]) : v[i][j];
-      t = ok ? t : 0.f;
-      v[i][j] = t;
-      m = fmaxf(m, fabsf(t));
+    for (int j = 0; j < 8; j += 2) {
+      float t0 = v[i][j], t1 = v[i][j + 1];
+      if (GELU) {
+#ifndef WANQ_QW_SCALAR_GELU
+        // gelu_tanh_fast_f32 on element PAIRS: the same operations, the plain ones as packed fp32 (bit-identical)
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const v2f x = {t0, t1}, c3 = {-0.10294324f, -0.10294324f}, c1 = {-2.3022082f, -2.3022082f}, one = {1.0f, 1.0f};
+        const v2f u = x * __builtin_elementwise_fma(x * x, c3, c1);
+        const v2f d = one + (v2f){__builtin_amdgcn_exp2f(u.x), __builtin_amdgcn_exp2f(u.y)};
+        const v2f r = x * (v2f){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+        t0 = r.x;
+        t1 = r.y;
+#else
+        t0 = gelu_tanh_fast_f32(t0);
+        t1 = gelu_tanh_fast_f32(t1);
+#endif
+      }
+      t0 = ok ? t0 : 0.f;
+      t1 = ok ? t1 : 0.f;
+      v[i][j] = t0;
+      v[i][j + 1] = t1;
+      m = fmaxf(m, fmaxf(fabsf(t0), fabsf(t1)));
     }
   }
   const float amax = wave_max(m);

@@ -241,12 +241,29 @@ __device__ __forceinline__ void quantN_pack_rne(const float (&x)[N], float s, fl
   static_assert(N % 4 == 0, "four codes per dword");
   float u[N];
   bool near = false;
+#ifndef WANQ_QUANT_SCALAR
+  // on element PAIRS (v_pk_fma_f32 / v_pk_add_f32: the same IEEE operations per half, bit-identical codes, 2.5 instead of 4
+  // vector instructions per element in front of the byte packing)
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f inv2 = {inv, inv}, magic2 = {WANQ_QMAGIC, WANQ_QMAGIC};
+#pragma unroll
+  for (int j = 0; j < N; j += 2) {
+    const v2f x2 = {x[j], x[j + 1]};
+    const v2f u2 = __builtin_elementwise_fma(x2, inv2, magic2);
+    const v2f d2 = __builtin_elementwise_fma(x2, inv2, -(u2 - magic2));
+    u[j] = u2.x;
+    u[j + 1] = u2.y;
+    near |= fabsf(d2.x) >= 0.4999488f;
+    near |= fabsf(d2.y) >= 0.4999488f;
+  }
+#else
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     u[j] = fmaf(x[j], inv, WANQ_QMAGIC);
     const float r = u[j] - WANQ_QMAGIC;
     near |= fabsf(fmaf(x[j], inv, -r)) >= 0.4999488f;
   }
+#endif
   if (near) {
 #pragma unroll
     for (int j = 0; j < N; ++j) u[j] = rintf(x[j] / s) + WANQ_QMAGIC;
