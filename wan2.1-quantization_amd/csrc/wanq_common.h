@@ -285,12 +285,27 @@ __device__ __forceinline__ void quantN_pack_rne_pre(const float (&y)[N], float c
   static_assert(N % 4 == 0, "four codes per dword");
   float u[N];
   bool near = false;
+#ifndef WANQ_QUANT_SCALAR
+  typedef float v2f __attribute__((ext_vector_type(2)));  // on element pairs, as in quantN_pack_rne
+  const v2f cinv2 = {cinv, cinv}, magic2 = {WANQ_QMAGIC, WANQ_QMAGIC};
+#pragma unroll
+  for (int j = 0; j < N; j += 2) {
+    const v2f y2 = {y[j], y[j + 1]};
+    const v2f u2 = __builtin_elementwise_fma(y2, cinv2, magic2);
+    const v2f d2 = __builtin_elementwise_fma(y2, cinv2, -(u2 - magic2));
+    u[j] = u2.x;
+    u[j + 1] = u2.y;
+    near |= fabsf(d2.x) >= 0.4999488f;
+    near |= fabsf(d2.y) >= 0.4999488f;
+  }
+#else
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     u[j] = fmaf(y[j], cinv, WANQ_QMAGIC);
     const float r = u[j] - WANQ_QMAGIC;
     near |= fabsf(fmaf(y[j], cinv, -r)) >= 0.4999488f;
   }
+#endif
   if (near) {
 #pragma unroll
     for (int j = 0; j < N; ++j) u[j] = rintf((y[j] * c) / s) + WANQ_QMAGIC;
