@@ -36,11 +36,13 @@ def main():
              5: "as 4 + s_nop 3 behind the wait", 6: "as 4, multiplier NOT in the loads' address register (no overwrite of v8)",
              7: "as 4, the multiply that reads A's last register FIRST behind the wait",
              8: "as 4, A's registers pre-filled with 5.0 (a stale read shows as 5.0, not 0)",
+             12: "as 4, the second packed multiply WITHOUT op_sel (lo = v8 * v12, hi = v9 * v13)",
+             13: "as 12 with v_pk_fma_f32 (+ 0) in place of v_pk_mul_f32",
              10: "as 4, the RESULT registers pre-filled with 9.0 (a lost write shows as 9.0)",
              11: "as 10, two plain v_mul_f32 in place of the second packed multiply",
              9: "as 4 + a plain v_mov of A's last register right behind the multiply, returned as 'A.x' (dword 0)"}
     for beside in (False, True):
-        for mode in ((4,) if "--pk0" in sys.argv else (10, 11) if "--pk3" in sys.argv else (8, 9) if "--pk2" in sys.argv else (4, 5, 6, 7) if "--pk" in sys.argv else (0, 1, 2, 3, 4)):
+        for mode in ((4, 12, 13) if "--pk4" in sys.argv else (4,) if "--pk0" in sys.argv else (10, 11) if "--pk3" in sys.argv else (8, 9) if "--pk2" in sys.argv else (4, 5, 6, 7) if "--pk" in sys.argv else (0, 1, 2, 3, 4)):
             early = torch.empty(per, rows, 64, 8, device="cuda")
             second = torch.empty(per, rows, 64, 4, device="cuda")
             where, vals, launches, bad_launches, bad_second = collections.Counter(), collections.Counter(), 0, 0, 0

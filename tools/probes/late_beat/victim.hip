@@ -82,6 +82,15 @@ __global__ __launch_bounds__(256) void victim_pk_kernel(const float* table, floa
   else if (VAR == 7)  // two plain v_mul_f32 in place of the second packed multiply
     asm volatile("v_mov_b32 v22, 0x41100000\n\tv_mov_b32 v23, 0x41100000\n\t"
                  PK_HEAD "v_mov_b32 v8, v3\n\ts_waitcnt vmcnt(1)\n\t" PK_MUL0 "v_mul_f32 v22, v8, v13\n\tv_mul_f32 v23, v8, v12\n\t" PK_TAIL PK_IO);
+  else if (VAR == 8)  // the packed multiply WITHOUT op_sel: v22 = v8 * v12, v23 = v9 * v13 (v9 = 1.0 too)
+    asm volatile(PK_HEAD "v_mov_b32 v8, v3\n\tv_mov_b32 v9, v3\n\ts_waitcnt vmcnt(1)\n\t" PK_MUL0
+                 "v_pk_mul_f32 v[22:23], v[8:9], v[12:13]\n\tv_mov_b32 v9, v22\n\tv_mov_b32 v22, v23\n\tv_mov_b32 v23, v9\n\t" PK_TAIL PK_IO);
+  else if (VAR == 9)  // v_pk_fma_f32 without op_sel on the same pair: v[22:23] = v[8:9] * v[12:13] + 0
+    asm volatile(PK_HEAD "v_mov_b32 v8, v3\n\tv_mov_b32 v9, v3\n\tv_mov_b32 v14, 0\n\tv_mov_b32 v15, 0\n\ts_waitcnt vmcnt(1)\n\t" PK_MUL0
+                 "v_pk_fma_f32 v[22:23], v[8:9], v[12:13], v[14:15]\n\tv_mov_b32 v9, v22\n\tv_mov_b32 v22, v23\n\tv_mov_b32 v23, v9\n\t" PK_TAIL
+                 : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+                 : "v"((uint32_t)(uintptr_t)p), "v"((uint32_t)((uintptr_t)p >> 32))
+                 : "memory", "v0", "v1", "v2", "v3", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v20", "v21", "v22", "v23", "v26", "v27", "v28", "v29");
   else  // a plain v_mov of v13 right BEHIND the packed multiply that reads it: returned in place of the B load's first register
     asm volatile(PK_HEAD "v_mov_b32 v8, v3\n\ts_waitcnt vmcnt(1)\n\t" PK_MUL0 PK_MUL1 "v_mov_b32 v21, v13\n\t" PK_TAIL PK_IO);
 
@@ -105,6 +114,8 @@ extern "C" int late_beat_victim(int mode, const float* table, float* early, floa
     case 9: hipLaunchKernelGGL(victim_pk_kernel<5>, grid, block, 0, st, table, early, rows); break;
     case 10: hipLaunchKernelGGL(victim_pk_kernel<6>, grid, block, 0, st, table, early, rows); break;
     case 11: hipLaunchKernelGGL(victim_pk_kernel<7>, grid, block, 0, st, table, early, rows); break;
+    case 12: hipLaunchKernelGGL(victim_pk_kernel<8>, grid, block, 0, st, table, early, rows); break;
+    case 13: hipLaunchKernelGGL(victim_pk_kernel<9>, grid, block, 0, st, table, early, rows); break;
     default: hipLaunchKernelGGL(victim_kernel<3>, grid, block, 0, st, table, early, second, rows); break;
   }
   return (int)hipGetLastError();
