@@ -667,6 +667,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define WANQ_ATTN_DMA_LATE 0
 #endif
 // timing-only ablations (wrong results; tools/probes/README.md): skip the lazy-rescale vote after the first tile / replace v_exp
+#ifndef WANQ_ATTN_NW4_KEYS_DEFAULT  // key count up to which the plain bf16 kernel runs in its 4-wave form
+#define WANQ_ATTN_NW4_KEYS_DEFAULT 1024
+#endif
 #ifndef WANQ_ABL_NODMA  // timing ablation (wrong results): no K / V tile is fetched inside the tile loop
 #define WANQ_ABL_NODMA 0
 #endif
@@ -680,10 +683,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #error "WANQ_ABL_* build deliberately wrong kernels (timing ablations): add -DWANQ_ALLOW_ABLATIONS, never in build.py's library"
 #endif
 
-template <bool SPLIT, bool QK8>
-__global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) {
+// NW = waves per workgroup: 8 (256 queries, three ring stages, tiles requested two ahead), or 4 (128 queries per workgroup,
+// two ring stages = 64 KiB, so that TWO workgroups share a CU: SIMD partners then belong to different workgroups and are not
+// coupled by the per-tile barrier; one's prologue / epilogue runs under the other's tiles).
+template <bool SPLIT, bool QK8, int NW = 8>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd16_kernel(const AttnParams p) {
   constexpr bool LSUM = WANQ_ATTN_LSUM_MFMA != 0 && !(SPLIT && !QK8);  // (the bf16 split-KV form has no 8 registers to spare: it spills)
   constexpr int STAGE = QK8 ? AT_STAGE8 : AT_STAGE;
+  constexpr int NST = NW == 8 ? 3 : 2, AHEAD = NST - 1;  // ring stages, prefetch distance in tiles
+  static_assert(NW == 8 || (NW == 4 && !SPLIT && !QK8), "the 4-wave form exists for the plain bf16 kernel only");
   constexpr int VOFF = QK8 ? AT_K8 : AT_TILE;  // byte offset of the V tile inside a stage
   typedef int v4i __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -697,7 +705,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
     head = i / nqb;
     qblk = i - head * nqb;
   }
-  const int q0 = qblk * AT_QB + wave * AT_QW;
+  const int q0 = qblk * (AT_QW * NW) + wave * AT_QW;
   const int nt = (p.Lk + AT_KB - 1) / AT_KB;
   // key tiles of this workgroup: all of them, or one contiguous share under split-KV (the host makes every share non-empty)
   const int jt0 = SPLIT ? (int)blockIdx.z * p.tiles_per_split : 0;
@@ -840,7 +848,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
     else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                                   \
   } while (0)
   A16_DMA(jt0, 0);
-  if (jt0 + 1 < jt1) {
+  if (AHEAD == 2 && jt0 + 1 < jt1) {
     A16_DMA(jt0 + 1, 1);
     A16_WAIT_TILE_AHEAD();
   } else {
@@ -849,14 +857,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
   __builtin_amdgcn_s_barrier();
   if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
 
-  for (int j0 = jt0; j0 < jt1; j0 += 3) {
+  for (int j0 = jt0; j0 < jt1; j0 += NST) {
 #pragma unroll
-  for (int u = 0; u < 3; ++u) {
+  for (int u = 0; u < NST; ++u) {
     const int j = j0 + u;
     if (j >= jt1) break;
     const char* sK = smem + u * STAGE;
     asm volatile("" : "+v"(d_k0), "+v"(d_k1), "+v"(d_k2), "+v"(d_k3), "+v"(d_v0), "+v"(d_v1), "+v"(d_v2), "+v"(d_v3));
-    if (!((WANQ_ATTN_DMA_LATE != 0) && (WANQ_ATTN_KASM != 0) && !QK8) && !WANQ_ABL_NODMA && j + 2 < jt1) A16_DMA(j + 2, (u + 2) % 3);
+    if (!((WANQ_ATTN_DMA_LATE != 0) && (WANQ_ATTN_KASM != 0) && !QK8) && !WANQ_ABL_NODMA && j + AHEAD < jt1) A16_DMA(j + AHEAD, (u + AHEAD) % NST);
 
     // ---------------- S^T blocks: fragment i = 4 kb + s read four ahead of its two MFMAs
     f32x4 sacc[4][2];
@@ -871,7 +879,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
 #define A16_KR(i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[i]) : "v"(((i) & 3) == 0 ? ka0 : ((i) & 3) == 1 ? ka1 : ((i) & 3) == 2 ? ka2 : ka3), "n"(((i) >> 2) * 4096))
 #pragma unroll
       for (int i = 0; i < KA; ++i) { A16_KR(i); }
-      if (WANQ_ATTN_DMA_LATE && !WANQ_ABL_NODMA && j + 2 < jt1) A16_DMA(j + 2, (u + 2) % 3);  // the first fragments fly under the DMA issue
+      if (WANQ_ATTN_DMA_LATE && !WANQ_ABL_NODMA && j + AHEAD < jt1) A16_DMA(j + AHEAD, (u + AHEAD) % NST);  // the first fragments fly under the DMA issue
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         if (i + KA < 16) { A16_KR(i + KA); }
@@ -1091,8 +1099,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(const AttnParams p) 
 #undef A16_PV
 #undef A16_F
     // tile j+1 must have landed; the eight instructions of tile j+2 (if issued; waves 4-7 issue none) may stay in flight
-    if (j + 2 < jt1) A16_WAIT_TILE_AHEAD();
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (AHEAD == 2 && j + 2 < jt1) A16_WAIT_TILE_AHEAD();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (two stages: the tile requested at the top of this one is the next)
     __builtin_amdgcn_s_barrier();
   }
   }
@@ -1205,6 +1213,7 @@ static bool use_m16() {
   static const bool m16 = [] {
     const char* e = getenv("WANQ_ATTN_M16");
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd16_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * AT_STAGE);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd16_kernel<false, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_STAGE);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd16_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * AT_STAGE);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd16_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * AT_STAGE8);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * AT_STAGE8);
@@ -1267,7 +1276,14 @@ static int attention_impl(const void* q, const void* k, const void* v, void* o, 
       (void)attr_v1;
       hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(512), 2 * AT_STAGE, st, p);
     } else if (use_m16()) {
-      hipLaunchKernelGGL((attn_fwd16_kernel<false, false>), grid, dim3(512), 3 * AT_STAGE, st, p);
+      // 4-wave workgroups of 128 queries, two per CU (see attn_fwd16_kernel), up to WANQ_ATTN_NW4_KEYS keys (0 = never)
+      static const int64_t nw4_keys = [] { const char* e = getenv("WANQ_ATTN_NW4_KEYS"); return e ? atoll(e) : (int64_t)WANQ_ATTN_NW4_KEYS_DEFAULT; }();
+      if (Lk <= nw4_keys) {
+        const dim3 grid4((unsigned)((Lq + 4 * AT_QW - 1) / (4 * AT_QW)), (unsigned)heads);
+        hipLaunchKernelGGL((attn_fwd16_kernel<false, false, 4>), grid4, dim3(256), 2 * AT_STAGE, st, p);
+      } else {
+        hipLaunchKernelGGL((attn_fwd16_kernel<false, false>), grid, dim3(512), 3 * AT_STAGE, st, p);
+      }
     } else {
       launch_attn<false, false>(p, grid, st);
     }
