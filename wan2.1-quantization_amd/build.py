@@ -5,6 +5,10 @@
 
 Each csrc/*.hip is compiled to build/<name>.o (skipped when the object is newer than the source and
 every header), then linked into lib/libwanq_hip.so.  No GPU is needed: hipcc cross-compiles.
+
+Every freshly compiled object goes through tools/isa_lint.py (disassembly of its gfx950 code object: the packed-fp32
+op_sel hazard of DESIGN.md 3.5, no spill inside the ping-pong GEMM's K loops, its store / LDS-DMA counts); an error fails
+the build before the library is linked.  WANQ_BUILD_LINT=0 skips it (A/B builds of deliberately different kernels).
 """
 import argparse
 import concurrent.futures as cf
@@ -37,6 +41,22 @@ def _compile(src, obj):
     return os.path.basename(src)
 
 
+def _lint(objs, verbose):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("wanq_isa_lint", os.path.join(HERE, "..", "tools", "isa_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    errors, lines, _ = lint.lint_objects(objs)
+    if verbose:
+        for ln in lines:
+            print(f"[wanq build] isa_lint {ln}", flush=True)
+    if errors:
+        for o in objs:  # so that the next build compiles (and lints) them again
+            if os.path.exists(o):
+                os.remove(o)
+        raise RuntimeError("isa_lint failed (tools/isa_lint.py):\n" + "\n".join(errors))
+
+
 def build(force=False, jobs=4, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
@@ -54,6 +74,8 @@ def build(force=False, jobs=4, verbose=True):
             for name in ex.map(lambda so: _compile(*so), todo):
                 if verbose:
                     print(f"[wanq build] compiled {name}", flush=True)
+        if os.environ.get("WANQ_BUILD_LINT", "1") != "0":
+            _lint([o for _, o in todo], verbose)
     if todo or not _newer(LIB, objs):
         r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs],
                            capture_output=True, text=True)
