@@ -55,6 +55,15 @@ int wanq_abi_version(void);
 int wanq_quant_rows(const void* x, int x_dtype, int8_t* q, void* scale, void* sum, int vec_dtype,
                     int64_t rows, int cols, int act, int static_amax, void* stream);
 
+/* The same per-token dynamic symmetric quantiser at a narrower range (codes still int8, the GEMMs are unchanged):
+ *   q[r,c] = rne(x[r,c] / scale_r),  scale_r = max(absmax_r / n_levels, floor),  n_levels = 2^(b-1) - 1 in [1, 127]
+ * floor = 0: no floor -- a row of zeros gets scale 0 and codes 0 (the reference divides 0 by 0 there and returns NaN).
+ * Replaces MixedPrecisionDynamicQuantizer.quantize, symmetric branch, at the active entry of its bit-width list
+ *   (quant_utils/qdiff/base/mixed_precision_quantizer.py:135-146,171-175: no eps floor) and DynamicQuantizer.quantize for
+ *   n_bits < 8 (base/base_quantizer.py:116-128,154-157: floor 1e-6).  Bit-identical codes and scales. */
+int wanq_quant_rows_levels(const void* x, int x_dtype, int8_t* q, void* scale, void* sum, int vec_dtype,
+                           int64_t rows, int cols, int n_levels, float floor, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm (no bias, optional gamma) -> optional adaLN modulate -> fp output OR int8 quant (+sum).
  *   y = (x - mean) * rstd * gamma;  y = y * (1 + mscale[b]) + mshift[b]   (b = row / rows_per_batch)

@@ -81,6 +81,39 @@ def dynamic_fake_quant_asym(x, n_bits=8):
     return ((q.astype(F32) + zp[:, None]) * delta[:, None]).astype(F32)
 
 
+# ------------------------------------------------------------------ A7 mixed-precision dynamic (list of bit-widths)
+def mixed_dynamic_quantize(x, n_bits, sym):
+    """MixedPrecisionDynamicQuantizer.quantize at the ACTIVE bit-width `n_bits` (Q/base/mixed_precision_quantizer.py:135-175;
+    `bitwidth_refactor(i)` :182-186 only selects `n_bits`, n_levels is recomputed per call :139).  Unlike DynamicQuantizer:
+    symmetric -- delta = absmax / (2**(b-1) - 1) with NO eps floor (:141-146), so an all-zero row gives 0 / 0 = NaN codes, exactly as
+    the reference (pinned with its NaNs by tests/golden/a7_mixed_dynamic.npz); asymmetric -- floor 1e-6 (:158-165; DynamicQuantizer
+    has 1e-8).  -> (x_quant fp32 with the reference's NaNs, delta fp32[T], zero_point fp32[T])."""
+    x = np.asarray(x, dtype=F32)
+    assert x.ndim == 2
+    with np.errstate(all="ignore"):
+        if sym:
+            n = 2 ** (n_bits - 1) - 1
+            delta = (np.abs(x).max(axis=1) / F32(n)).astype(F32)
+            zp = np.zeros_like(delta)
+        else:
+            n = 2 ** n_bits
+            hi = np.maximum(x.max(axis=1), F32(0)).astype(F32)
+            lo = np.minimum(x.min(axis=1), F32(0)).astype(F32)
+            delta = ((hi - lo) / F32(n - 1)).astype(F32)
+            delta = np.where(delta < F32(1e-6), F32(1e-6), delta).astype(F32)
+            zp = (np.round((lo / delta).astype(F32)) + F32(n / 2)).astype(F32)
+        q = np.round((x / delta[:, None]).astype(F32)) - zp[:, None]
+        q = np.where(np.isnan(q), q, np.clip(q, -n - 1, n)).astype(F32)  # torch.clamp keeps NaN
+    return q, delta, zp
+
+
+def mixed_dynamic_fake_quant(x, n_bits, sym):
+    """MixedPrecisionDynamicQuantizer.forward: (x_quant + zero_point) * delta.  Q/base/mixed_precision_quantizer.py:177-180."""
+    q, delta, zp = mixed_dynamic_quantize(x, n_bits, sym)
+    with np.errstate(all="ignore"):
+        return ((q + zp[:, None]) * delta[:, None]).astype(F32)
+
+
 # ------------------------------------------------------------------ A1 static per-channel
 def static_quant_params(w, n_bits=8, sym=False):
     """StaticQuantizer.init_quant_params.  Q/base/base_quantizer.py:70-99.

@@ -512,3 +512,105 @@ def test_dynamic_quantizer_asymmetric_branch_vs_reference_golden(golden):
     ql.w_quantizer.init_done = True
     y = ql(x.unsqueeze(0))[0].float().cpu().numpy()
     assert np.abs(y - g["y"]).max() < 2e-5 * np.abs(g["y"]).max() + 2e-5
+
+
+@pytest.mark.parametrize("sym", [True, False])
+def test_mixed_precision_dynamic_quantizer_vs_reference_golden(golden, sym):
+    """qdiff.MixedPrecisionDynamicQuantizer (Q/base/mixed_precision_quantizer.py:126-186) on the HIP quantise kernels at every entry
+    of its bit-width list [8, 6, 4], `bitwidth_refactor` between calls: codes, delta, zero point and dequantised values BIT FOR BIT
+    against the reference's own class (tests/golden/make_golden_mixed_dynamic.py), including the tiny row that keeps its own delta
+    (no eps floor in the symmetric branch) and the asymmetric floor 1e-6.  The all-zero row is where the reference is undefined
+    (0 / 0: NaN codes): here delta 0, codes 0, output 0."""
+    from qdiff import config as qcfg
+    from qdiff.base.mixed_precision_quantizer import MixedPrecisionDynamicQuantizer
+
+    g = golden("a7_mixed_dynamic")
+    tag = "sym" if sym else "asym"
+    x = t(g["x"], torch.float32)
+    mq = MixedPrecisionDynamicQuantizer(qcfg.create({"n_bits": [8, 6, 4], "i_bitwidth": 0, "sym": sym}))
+    ok = np.array([r for r in range(x.shape[0]) if not (sym and r == 5)])
+    for i, bits in list(enumerate((8, 6, 4))) + [(0, 8)]:
+        mq.bitwidth_refactor(i)
+        assert mq.n_bits == bits
+        codes = mq.quantize(x).cpu().numpy()
+        delta, zp = mq.delta.reshape(-1).cpu().numpy(), mq.zero_point.reshape(-1).cpu().numpy()
+        deq = mq(x).cpu().numpy()
+        assert np.array_equal(delta[ok], g[f"{tag}_delta{bits}"][ok]) and np.array_equal(zp[ok], g[f"{tag}_zp{bits}"][ok])
+        assert np.array_equal(codes[ok], g[f"{tag}_q{bits}"][ok])
+        assert np.array_equal(deq[ok], g[f"{tag}_dequant{bits}"][ok])
+        if sym:
+            assert np.isnan(g[f"{tag}_q{bits}"][5]).all()                      # the reference: NaN
+            assert delta[5] == 0 and not codes[5].any() and not deq[5].any()   # here: zeros
+            assert 0 < delta[4] < 1e-6 and np.abs(codes[4]).max() == 2 ** (bits - 1) - 1
+        else:
+            assert delta[4] == np.float32(1e-6) and delta[5] == np.float32(1e-6)
+
+
+@pytest.mark.parametrize("bits", [6, 4, 2])
+def test_dynamic_quantizer_below_8_bits_and_quantized_linear_with_a_bitwidth_list(golden, bits):
+    """Activation n_bits < 8 on the int8 path (the codes fit int8, only the range changes, the GEMM is unchanged):
+    DynamicQuantizer codes / scales bit-exact against the oracle (eps floor 1e-6 kept: base_quantizer.py:122-127) for fp32 / bf16 /
+    fp16 rows of several widths; and a QuantizedLinear whose activation n_bits is a list (-> MixedPrecisionDynamicQuantizer,
+    quant_layer.py:48-52) against the reference layer's own output at 6 bits."""
+    from qdiff import config as qcfg
+    from qdiff.base.base_quantizer import DynamicQuantizer
+    from qdiff.base.mixed_precision_quantizer import MixedPrecisionDynamicQuantizer
+    from qdiff.base.quant_layer import QuantizedLinear
+
+    gen = torch.Generator().manual_seed(bits)
+    for rows, cols, dt in [(33, 1536, torch.float32), (7, 5120, torch.bfloat16), (5, 8960, torch.float16), (9, 64, torch.float32)]:
+        x = (torch.randn(rows, cols, generator=gen) * torch.exp(0.5 * torch.randn(cols, generator=gen))).to(dt)
+        x[0] = 0
+        x[1] *= 1e-8
+        dq = DynamicQuantizer(qcfg.create({"n_bits": bits, "sym": True}))
+        q, scale, ssum = dq.quantize_int8(x.to(DEV))
+        oq, od = qr.dynamic_quantize_sym(x.float().numpy(), bits)
+        assert np.array_equal(scale.cpu().numpy(), od) and np.array_equal(q.cpu().numpy().astype(np.int32), oq)
+        assert np.abs(q.cpu().numpy()).max() == 2 ** (bits - 1) - 1 and od[0] == np.float32(1e-6)
+        np.testing.assert_allclose(ssum.cpu().numpy(), oq.sum(axis=1) * od, rtol=1e-6, atol=1e-12)
+        assert np.array_equal(dq(x.to(DEV)).cpu().numpy(), qr.dynamic_fake_quant_sym(x.float().numpy(), bits))
+    if bits == 6:
+        g = golden("a7_mixed_dynamic")
+        lin = torch.nn.Linear(256, 24).to(DEV)
+        lin.weight.data, lin.bias.data = t(g["w"], torch.float32), t(g["b"], torch.float32)
+        conf = qcfg.create({"weight": {"n_bits": 8, "sym": False}, "act": {"n_bits": [8, 6, 4], "i_bitwidth": 1, "sym": True}})
+        ql = QuantizedLinear(256, 24, True, DEV, conf, lin)
+        assert isinstance(ql.a_quantizer, MixedPrecisionDynamicQuantizer) and ql.a_quantizer.n_bits == 6
+        ql.w_quantizer.init_done = True
+        y = ql(t(g["x"][g["lin_rows"]], torch.float32).unsqueeze(0))[0].float().cpu().numpy()
+        assert np.abs(y - g["y6"]).max() < 2e-5 * np.abs(g["y6"]).max() + 2e-5
+
+
+@pytest.mark.parametrize("act", [{"n_bits": 8, "sym": False}, {"n_bits": 6, "sym": True}, {"n_bits": [8, 4], "i_bitwidth": 1, "sym": False}])
+def test_viditq_linear_with_asymmetric_or_narrow_activations_vs_oracle(golden, act):
+    """ViDiTQuantizedLinear accepts any activation quantiser in the reference (viditq_quant_layer.py:60-73: mask, fp64 rotation, then
+    `self.a_quantizer`): asymmetric (base_quantizer.py:130-149), below 8 bits, or a bit-width list.  Here the transformed row is
+    written in fp32 and quantised by the plain kernels; checked against the oracle's definition evaluated in float64 on the
+    reference-made layer of golden a4_viditq_1536 (same weights, mask and signs): layer output at the level of one activation step."""
+    from qdiff import config as qcfg
+    from qdiff.viditq.viditq_quant_layer import ViDiTQuantizedLinear
+
+    g = golden("a4_viditq_1536")
+    n, out = 1536, 24
+    lin = torch.nn.Linear(n, out).to(DEV)
+    lin.weight.data, lin.bias.data = t(g["w"]), t(g["b"])
+    conf = qcfg.create({"weight": {"n_bits": 8, "sym": False}, "act": act, "viditq": {"alpha": 0.5665, "layer_name_regex": ""}})
+    vl = ViDiTQuantizedLinear(n, out, True, DEV, conf, lin)
+    vl.channel_mask = t(g["channel_mask"])
+    vl.rotation_signs = torch.from_numpy(g["signs"])
+    vl.update_quantized_weight_rotated_and_scaled()
+    assert np.array_equal(vl.weight.data.cpu().numpy(), g["w_final"])
+    x = g["x"].reshape(-1, n)
+    y = vl(t(g["x"])).float().cpu().numpy().reshape(-1, out)
+    # oracle: x' = (x * mask) @ R in float64 -> fp32, the configured quantiser, then x_dq . w_final^T + b
+    R = qr.hadamard_from_signs(g["signs"])
+    xt = ((x.astype(np.float64) * g["channel_mask"].astype(np.float64)) @ R).astype(np.float32)
+    bits = act["n_bits"] if isinstance(act["n_bits"], int) else act["n_bits"][act["i_bitwidth"]]
+    if isinstance(act["n_bits"], int):
+        xdq = qr.dynamic_fake_quant_asym(xt, bits) if not act["sym"] else qr.dynamic_fake_quant_sym(xt, bits)
+    else:
+        xdq = qr.mixed_dynamic_fake_quant(xt, bits, act["sym"])
+    want = xdq.astype(np.float64) @ g["w_final"].astype(np.float64).T + g["b"]
+    step = np.abs(xt).max(axis=1).max() / (2 ** (bits - 1))   # one activation step
+    assert np.abs(y - want).max() < 0.02 * step * np.abs(g["w_final"]).sum(axis=1).max() + 1e-3
+    assert np.linalg.norm(y - want) / np.linalg.norm(want) < 2e-3

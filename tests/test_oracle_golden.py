@@ -280,6 +280,34 @@ def test_a2_dynamic_quantizer_asymmetric_branch_vs_reference(golden, bits):
         assert np.abs(y - g["y"]).max() < 2e-5 * np.abs(g["y"]).max()
 
 
+@pytest.mark.parametrize("sym", [True, False])
+@pytest.mark.parametrize("bits", [8, 6, 4])
+def test_a7_mixed_precision_dynamic_quantizer_vs_reference(golden, bits, sym):
+    """The reference's MixedPrecisionDynamicQuantizer (mixed_precision_quantizer.py:126-186) at each entry of its bit-width list
+    (`bitwidth_refactor` between calls), symmetric and asymmetric: codes, delta, zero point and dequantised values bit for bit --
+    INCLUDING the all-zero row, where the symmetric branch has no eps floor and the reference's 0 / 0 gives NaN codes."""
+    g = golden("a7_mixed_dynamic")
+    tag = "sym" if sym else "asym"
+    q, delta, zp = qr.mixed_dynamic_quantize(g["x"], bits, sym)
+    assert np.array_equal(delta, g[f"{tag}_delta{bits}"]) and np.array_equal(zp, g[f"{tag}_zp{bits}"], equal_nan=True)
+    assert np.array_equal(q, g[f"{tag}_q{bits}"], equal_nan=True)
+    assert np.array_equal(qr.mixed_dynamic_fake_quant(g["x"], bits, sym), g[f"{tag}_dequant{bits}"], equal_nan=True)
+    nan_rows = np.unique(np.argwhere(np.isnan(g[f"{tag}_q{bits}"]))[:, 0]).tolist()
+    assert nan_rows == ([5] if sym else [])          # only the all-zero row, only without a floor
+    if sym:
+        assert delta[4] < 1e-6 and delta[4] > 0      # the tiny row keeps its own delta (DynamicQuantizer would floor it at 1e-6)
+        assert np.abs(q[4]).max() == 2 ** (bits - 1) - 1
+    else:
+        assert delta[4] == np.float32(1e-6) and delta[5] == np.float32(1e-6)   # eps = 1e-6 here (DynamicQuantizer: 1e-8)
+    if bits == 8:  # the parameters depend on the active entry only, not on the refactor history
+        assert np.array_equal(g[f"{tag}_q8_again"], g[f"{tag}_q8"], equal_nan=True)
+    if sym and bits == 6:  # a QuantizedLinear whose activation n_bits is a list, entry 1 = 6 bits (quant_layer.py:48-52)
+        rows = g["lin_rows"]
+        wdq = qr.static_fake_quant(g["w"], 8, False)[0]
+        y = qr.mixed_dynamic_fake_quant(g["x"][rows], 6, True).astype(np.float64) @ wdq.astype(np.float64).T + g["b"]
+        assert np.abs(y - g["y6"]).max() < 2e-5 * np.abs(g["y6"]).max()
+
+
 def test_block_oracle_on_sampled_rows_equals_the_full_block():
     """BlockRef.rows (what the headline-size block test compares against) == BlockRef.__call__ on those rows: every step but the
     self-attention keys / values is row-local.  ViDiT layers on q / k / v as in the headline configuration."""

@@ -36,6 +36,9 @@ struct RowParams {
   int act;
   int static_amax;
   const float* premul;  // [cols] fp32 multiplier applied before quantisation (SmoothQuant channel mask), or NULL
+  // dynamic quantiser range: scale = absmax / levels floored at `floor` (127 and 1e-6 for every 8-bit entry point;
+  // wanq_quant_rows_levels: 2^(b-1) - 1 and the caller's floor, 0 = none: a zero row then gets scale 0 and codes 0)
+  float levels, floor;
 };
 
 __device__ __forceinline__ void load8_rt(const void* base, int dt, int64_t elem, float (&v)[8]) {
@@ -215,9 +218,9 @@ __global__ __launch_bounds__(256) void rowwise_kernel(const RowParams p) {
       for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[i][j]));
     amax = red.max(m, 2);
   }
-  float scale = amax / 127.0f;
-  if (scale < 1e-6f) scale = 1e-6f;  // qdiff eps rule (base_quantizer.py:122-127)
-  const float inv = 1.0f / scale;
+  float scale = amax / p.levels;
+  if (scale < p.floor) scale = p.floor;  // qdiff eps rule (base_quantizer.py:122-127)
+  const float inv = scale > 0.f ? 1.0f / scale : 0.f;  // (no floor and an all-zero row: every code is 0)
   int isum = 0;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
@@ -513,6 +516,7 @@ int premul_quant_rows(bool ln, const void* x, int x_dtype, const void* gamma, co
   if (int e = check_rows_cols(what, rows, cols)) return e;
   if (rows == 0) return WANQ_OK;
   RowParams p{};
+  p.levels = 127.0f; p.floor = 1e-6f;
   p.x = x; p.x_dtype = x_dtype; p.gamma = gamma; p.mshift = mshift; p.mscale = mscale; p.mod_dtype = WANQ_F32;
   p.mod_stride = mod_stride; p.rows_per_batch = rows_per_batch; p.eps = eps; p.out_fp = out_fp; p.out_dtype = out_dtype;
   p.q = q; p.scale = scale; p.sum = sum; p.vec_dtype = vec_dtype; p.rows = rows; p.cols = cols; p.premul = premul;
@@ -573,9 +577,24 @@ extern "C" int wanq_quant_rows(const void* x, int x_dtype, int8_t* q, void* scal
   if (!static_amax && launch_quant_rows_wave(x, x_dtype, q, scale, sum, vec_dtype, rows, cols, act, (hipStream_t)stream))
     return check_launch("wanq_quant_rows");
   RowParams p{};
+  p.levels = 127.0f; p.floor = 1e-6f;
   p.x = x; p.x_dtype = x_dtype; p.q = q; p.scale = scale; p.sum = sum; p.vec_dtype = vec_dtype;
   p.rows = rows; p.cols = cols; p.act = act; p.static_amax = static_amax; p.rows_per_batch = 1;
   return launch_rowwise<false>(p, (hipStream_t)stream, "wanq_quant_rows");
+}
+
+extern "C" int wanq_quant_rows_levels(const void* x, int x_dtype, int8_t* q, void* scale, void* sum, int vec_dtype, int64_t rows,
+                                      int cols, int n_levels, float floor, void* stream) {
+  WANQ_REQUIRE(x && q && scale, WANQ_E_ARG, "wanq_quant_rows_levels: x, q and scale must be non-NULL");
+  WANQ_REQUIRE(is_fp(x_dtype) && is_vec(vec_dtype), WANQ_E_ARG, "wanq_quant_rows_levels: bad dtype code (x=%d vec=%d)", x_dtype, vec_dtype);
+  WANQ_REQUIRE(n_levels >= 1 && n_levels <= 127, WANQ_E_ARG, "wanq_quant_rows_levels: n_levels=%d must be in [1, 127] (int8 codes)", n_levels);
+  WANQ_REQUIRE(floor >= 0.f && floor == floor, WANQ_E_ARG, "wanq_quant_rows_levels: floor must be >= 0");
+  if (int e = check_rows_cols("wanq_quant_rows_levels", rows, cols)) return e;
+  if (rows == 0) return WANQ_OK;
+  RowParams p{};
+  p.x = x; p.x_dtype = x_dtype; p.q = q; p.scale = scale; p.sum = sum; p.vec_dtype = vec_dtype;
+  p.rows = rows; p.cols = cols; p.rows_per_batch = 1; p.levels = (float)n_levels; p.floor = floor;
+  return launch_rowwise<false>(p, (hipStream_t)stream, "wanq_quant_rows_levels");
 }
 
 extern "C" int wanq_layernorm_rows(const void* x, int x_dtype, const void* gamma, const void* mshift,
@@ -591,6 +610,7 @@ extern "C" int wanq_layernorm_rows(const void* x, int x_dtype, const void* gamma
   if (int e = check_rows_cols("wanq_layernorm_rows", rows, cols)) return e;
   if (rows == 0) return WANQ_OK;
   RowParams p{};
+  p.levels = 127.0f; p.floor = 1e-6f;
   p.x = x; p.x_dtype = x_dtype; p.gamma = gamma; p.mshift = mshift; p.mscale = mscale; p.mod_dtype = mod_dtype;
   p.mod_stride = mod_stride; p.rows_per_batch = rows_per_batch; p.eps = eps; p.out_fp = out_fp; p.out_dtype = out_dtype;
   p.q = q; p.scale = scale; p.sum = sum; p.vec_dtype = vec_dtype; p.rows = rows; p.cols = cols;

@@ -13,4 +13,4 @@ void set_error(const char* fmt, ...) {
 }  // namespace wanq
 
 extern "C" const char* wanq_last_error(void) { return wanq::g_err; }
-extern "C" int wanq_abi_version(void) { return 5; }
+extern "C" int wanq_abi_version(void) { return 6; }

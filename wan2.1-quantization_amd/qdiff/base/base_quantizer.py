@@ -81,16 +81,15 @@ class DynamicQuantizer(BaseQuantizer):
     tests/golden/a2_dynamic_asym.npz): the row minimum / maximum, delta and zero point are those of the static asymmetric
     quantiser evaluated per call (same equations, eps floor 1e-8), on the same HIP kernels (row_minmax + weight_quant)."""
 
-    def _check(self):
-        if self.n_bits != 8:
-            raise NotImplementedError("the int8 activation path implements 8-bit per-token quantisation")
+    # eps floors of delta: symmetric (:122-127) / asymmetric (:139-146).  MixedPrecisionDynamicQuantizer overrides both.
+    _sym_floor, _asym_floor = 1e-6, 1e-8
 
     # ---- asymmetric branch ------------------------------------------------------------------------
     def _asym_params(self, x):
         lo, hi, _ = fused.row_minmax(x)
         hi, lo = hi.clamp_min(0.0), lo.clamp_max(0.0)
         delta = (hi - lo) / _full(hi, self.n_levels - 1)
-        delta = torch.where(delta < 1e-8, _full(delta, 1e-8), delta)  # (the reference drops into ipdb first, then floors: :139-146)
+        delta = torch.where(delta < self._asym_floor, _full(delta, self._asym_floor), delta)  # (the reference drops into ipdb first, then floors: :139-146)
         zp = torch.round(lo / delta) + self.n_levels / 2
         self.delta, self.zero_point = delta.unsqueeze(-1), zp.unsqueeze(-1)
         return delta.contiguous(), zp.contiguous()
@@ -105,17 +104,31 @@ class DynamicQuantizer(BaseQuantizer):
         """int8 codes + fp32 (scale [T], sum [T]).  premul / rotation = (had_k, hadk): the ViDiT transform fused in.
         Asymmetric: the per-token zero point is left in `self.zero_point`; the caller adds its rank-one term
         (QuantizedLinear.forward).  int8 storage saturates the code 128 the reference's loose clamp admits at an exact tie (D9)."""
-        self._check()
         x = x.contiguous()
         rows = x.shape[0]
         if not self.sym:
             if premul is not None or rotation is not None:
-                raise NotImplementedError("asymmetric activations under a ViDiT / QuaRot / SmoothQuant transform are not implemented")
+                # (x * mask) @ R first, in fp32, then the asymmetric quantiser on the transformed row, as the reference's
+                # ViDiTQuantizedLinear.forward orders it (viditq_quant_layer.py:60-73 with base_quantizer.py:130-149)
+                y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+                fused.rotate_quant(x, premul, rotation, None, None, out_fp=y, quantize=False)
+                x = y
             codes, _ = self._asym(x, True, False, -128, 127)
             scale = self.delta.reshape(-1).float().contiguous()
             return codes, scale, (codes.float().sum(dim=1) * scale) if want_sum else None
         qs = torch.empty(2, rows, dtype=torch.float32, device=x.device)
-        if premul is None and rotation is None:
+        if self.n_bits != 8 or self._sym_floor != 1e-6:
+            # any other range (n_bits < 8; the mixed-precision class has no floor): codes still fit int8 and the GEMM is unchanged.
+            # Under a transform the transformed row is written out in fp32 first and quantised by the plain kernel (simulation
+            # mode only: kernel-mode activations are always 8-bit)
+            if not 2 <= self.n_bits <= 8:
+                raise NotImplementedError(f"int8 activation codes hold 2..8 bits, not {self.n_bits}")
+            if premul is not None or rotation is not None:
+                y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+                fused.rotate_quant(x, premul, rotation, None, None, out_fp=y, quantize=False)
+                x = y
+            q = fused.quant_sum_levels(x, qs[1] if want_sum else None, qs[0], 2 ** (self.n_bits - 1) - 1, self._sym_floor)
+        elif premul is None and rotation is None:
             q = fused.quant_sum(x, qs[1] if want_sum else None, qs[0])
         else:
             q = fused.rotate_quant(x, premul, rotation, qs[1] if want_sum else None, qs[0])
@@ -126,12 +139,10 @@ class DynamicQuantizer(BaseQuantizer):
         assert x.dim() == 2
         if not self.sym:  # (8 bits: codes live in int8 storage, which saturates the 2^b-th level of the reference's loose clamp, D9)
             return self._asym(x, True, False, *((-128, 127) if self.n_bits == 8 else (None, None)))[0].float()
-        self._check()
         return self.quantize_int8(x, want_sum=False)[0].float()
 
     def forward(self, x):
         if not self.sym:
             return self._asym(x, False, True)[1]
-        self._check()
         q, scale, _ = self.quantize_int8(x, want_sum=False)
         return q.float() * scale.unsqueeze(-1)

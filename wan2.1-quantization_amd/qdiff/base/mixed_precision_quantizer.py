@@ -34,6 +34,13 @@ class MixedPrecisionStaticQuantizer(StaticQuantizer):
 
 
 class MixedPrecisionDynamicQuantizer(DynamicQuantizer):
+    """mixed_precision_quantizer.py:126-186: the per-token dynamic quantiser at the ACTIVE entry of a bit-width list (n_levels is
+    recomputed from it on every call, :139).  Two differences from DynamicQuantizer, pinned by tests/golden/a7_mixed_dynamic.npz:
+    the symmetric branch has NO eps floor (:141-146) -- a tiny row keeps its own delta -- and the asymmetric floor is 1e-6
+    (:158-165), not 1e-8.  Where the reference is undefined -- an all-zero row in the symmetric branch is 0 / 0: NaN codes, NaN
+    output -- this class returns delta 0, codes 0, output 0 (repo-defined; SURVEY D5's rule for behaviour the reference breaks)."""
+    _sym_floor, _asym_floor = 0.0, 1e-6
+
     def __init__(self, quant_config):
         BaseQuantizer.__init__(self, quant_config)
         assert isinstance(quant_config["n_bits"], ListConfig) and quant_config.get("i_bitwidth", None) is not None

@@ -26,13 +26,14 @@ lib = ctypes.CDLL(LIB_PATH)
 
 F16, BF16, F32, I32, I16 = 0, 1, 2, 3, 4
 EPI_GELU, EPI_GATE_RES = 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
 # name -> argtypes, exactly include/wanq_hip.h
 PROTOTYPES = {
     "wanq_quant_rows": [_vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp],
+    "wanq_quant_rows_levels": [_vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _vp],
     "wanq_layernorm_rows": [_vp, _i, _vp, _vp, _vp, _i, _i64, _i64, _f, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _vp],
     "wanq_gate_residual": [_vp, _i, _vp, _i, _i64, _vp, _i, _vp, _i, _i64, _i, _i64, _vp],
     "wanq_gemm_w8a8": [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i64, _i, _i, _vp],

@@ -51,6 +51,23 @@ def quant_sum(input, sum_output, scaling):
     return _quant_rows(input, sum_output, scaling, 0, 0)
 
 
+def quant_sum_levels(input, sum_output, scaling, n_levels, floor=1e-6):
+    """quant_sum at a narrower symmetric range: codes rne(x / scale), scale = max(absmax / n_levels, floor), n_levels = 2^(b-1) - 1
+    (the activation quantisers at n_bits < 8 and MixedPrecisionDynamicQuantizer, whose symmetric branch has floor = 0)."""
+    rows, cols = _rows_cols("input", input)
+    _check_vec("scaling", scaling, rows)
+    if sum_output is not None:
+        _check_vec("sum_output", sum_output, rows)
+        if sum_output.dtype != scaling.dtype:
+            raise RuntimeError("sum_output and scaling must share a dtype")
+    _C.check_same_device(input, sum_output, scaling)
+    out = torch.empty(input.shape, dtype=torch.int8, device=input.device)
+    with torch.cuda.device(input.device):
+        _C.call("wanq_quant_rows_levels", _C.ptr(input), _C.dt(input), _C.ptr(out), _C.ptr(scaling), _C.ptr(sum_output),
+                _C.dt(scaling), rows, cols, int(n_levels), float(floor), _C.stream())
+    return out
+
+
 def quant_sum_static(input, sum_output, scaling):
     """Like quant_sum, but `scaling` is an INPUT holding the per-row absmax (reference fused.cu:84-86)."""
     return _quant_rows(input, sum_output, scaling, 0, 1)

@@ -129,6 +129,9 @@ def _to_hip_linear(lin, n_bits, sym, act_dtype):
             if not lin.a_quantizer.sym:
                 raise NotImplementedError("kernel mode: the fused producers quantise activations symmetrically per token (every Wan "
                                           "configuration); asymmetric activations run in simulation mode (qdiff.QuantizedLinear)")
+            if lin.a_quantizer.n_bits != 8:
+                raise NotImplementedError(f"kernel mode: the fused producers emit 8-bit activation codes (W8A8 / W4A8, as the reference's "
+                                          f"kernels: fused.cu:330-370); {lin.a_quantizer.n_bits}-bit activations run in simulation mode")
             return HipLinearW8A8.from_quantized(lin)
         lin = lin.fp_module
     if n_bits is None:
