@@ -20,6 +20,7 @@ sys.path.insert(0, os.path.join(ROOT, "wan2.1-quantization_amd"))
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+HBM_PEAK = 8.0e12        # HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured with a float4 copy)
 BF16_MFMA_PEAK = 2.5e15   # dense bf16 FLOP/s (same guide; a bare register-only MFMA stream sustains 1.8e15 here: tools/probes)
 INT8_MFMA_PEAK = 5.03e15  # dense int8 op/s: 2048 op/clk/SIMD x 4 SIMD x 256 CU x 2.4 GHz (MI355X_MICROARCH.md, Matrix cores)
 
@@ -78,8 +79,8 @@ def cpu_baseline(cfg, L, n_vidit_per_block=3, rows=1024, reps=3):
     from oracle import qdiff_ref as qr
     from oracle import wan_ref as wr
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-    cores = max(1, min(cores, 64))
+    cores_available = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    cores = max(1, min(cores_available, 64))  # torch's intra-op pool gains nothing past 64 threads on these GEMM sizes
     torch.set_num_threads(cores)
     C, Fd, H = cfg["dim"], cfg["ffn_dim"], cfg["num_heads"]
     g = torch.Generator().manual_seed(0)
@@ -147,7 +148,7 @@ def cpu_baseline(cfg, L, n_vidit_per_block=3, rows=1024, reps=3):
     t_blk = median_time(lambda: blk(xa, e0, grid_a, La, ctx, freqs))
     step_a = t_blk * cfg["num_layers"] * 2
     vd = f"ViDiT scale + fp64 rotation on {n_vidit_per_block} of them" if n_vidit_per_block else "no ViDiT layers"
-    return dict(value=1.0 / step_s, unit="steps/s", cores=cores, kind="port",
+    return dict(value=1.0 / step_s, unit="steps/s", cores=cores, cores_available=cores_available, kind="port",
                 sample=f"{rows}-token row slice of one fake-quant DiT block at L={L} (10 fake-quant Linears, {vd}, + fp32 "
                        f"attention {rows}x{L}x{H} heads), median of {reps}: {t_slice:.3f}s, scaled x{L / rows:.1f} x{cfg['num_layers']} blocks x2 passes",
                 cfg_a={"value": 1.0 / step_a, "unit": "steps/s", "workload": f"832*480 9f (L={La})",
@@ -215,16 +216,17 @@ def main():
                  f"torch.distributed.run with --nproc-per-node equal to --gpus)")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the quantized hot path has no CPU fallback)"
     # Rehearsal of the N > 1 control flow on a ONE-GPU box (RCCL refuses two ranks on one device): all ranks share cuda:0,
-    # rendezvous over gloo, and the collectives are staged through host memory (wan/distributed/rehearsal.py).  Never a measurement.
-    rehearse = world > 1 and os.environ.get("WANQ_BENCH_REHEARSE_ON_ONE_GPU") == "1"
+    # rendezvous over gloo, and the collectives are staged through host memory (tools/one_gpu_rehearsal.py).  Never a measurement;
+    # refused (exit 4) when the box shows more than one GPU, so the variable cannot turn a real N > 1 run into gloo by accident.
+    from wan.distributed import enter_one_gpu_rehearsal, stage_rehearsal_collectives
+    rehearse = enter_one_gpu_rehearsal("WANQ_BENCH_REHEARSE_ON_ONE_GPU", world)
     if rehearse:
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if rehearse:
         dist.init_process_group("gloo", init_method="env://")
-        from wan.distributed.rehearsal import stage_collectives_through_host
-        stage_collectives_through_host()
+        stage_rehearsal_collectives()
     elif world > 1:
         try:
             dist.init_process_group("nccl", init_method="env://", device_id=dev)
@@ -268,6 +270,29 @@ def main():
     hooks = calib.add_hooks(fp)
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         fp([latent0], sched.timesteps[0:1], [ctx_c], seq_len_for(shape))
+    # BASELINE config 3's hot reduction, timed: the SAME hooked FP pass once more (the running per-channel maxima are idempotent
+    # under a repeat of the same input), wall time of the pass + a HIP event pair around every wanq_col_absmax launch
+    # (W/get_calib_data_wanx.py:262-267: one per-channel absmax of every Linear input per call)
+    from viditq_extension import _C as wanq_C
+    calib_report = None
+    if rank == 0:
+        ctimer = {}
+        wanq_C.set_call_timer(ctimer)
+        torch.cuda.synchronize()
+        tc0 = time.perf_counter()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            fp([latent0], sched.timesteps[0:1], [ctx_c], seq_len_for(shape))
+        torch.cuda.synchronize()
+        calib_ms = (time.perf_counter() - tc0) * 1e3
+        wanq_C.set_call_timer(None)
+        ev = ctimer.get("col_absmax", [])
+        if ev:
+            k_s = sum(a.elapsed_time(b) for a, b, _ in ev) * 1e-3
+            k_b = float(sum(n for _, _, n in ev))
+            calib_report = {"what": "one hooked FP (bf16 autocast) DiT pass at the timed workload's size: per-channel absmax of every Linear input "
+                                    "(wanq_col_absmax, running maxima kept on the device)",
+                            "ms_per_pass": calib_ms, "absmax_launches": len(ev), "absmax_bytes": k_b, "absmax_ms": k_s * 1e3,
+                            "absmax_TBps": k_b / k_s / 1e12, "frac_of_8TBps": k_b / k_s / HBM_PEAK}
     calib_data = calib.gather_and_save_activation(hooks)
     gen = torch.Generator().manual_seed(0)
     n_vidit = 0
@@ -346,6 +371,8 @@ def main():
     atimer = GemmTimer()
     qgemm.set_timer(timer)
     wan_ops.set_attention_timer(atimer)
+    htimer = {}
+    wanq_C.set_call_timer(htimer)  # the HBM-bound row-wise kernels of the step (an event pair around each launch)
     torch.cuda.synchronize()
     tp0 = time.perf_counter()
     for i in range(total, total + args.steps):
@@ -354,6 +381,7 @@ def main():
     dt_prof = time.perf_counter() - tp0
     qgemm.set_timer(None)
     wan_ops.set_attention_timer(None)
+    wanq_C.set_call_timer(None)
 
     gs = timer.summary()
     out = {
@@ -368,7 +396,8 @@ def main():
                    "context_kv": "cross_attn.k / .v of the text context computed once per context tensor (step-invariant), reused by every step"
                                  if model.context_cache else "cross_attn.k / .v of the text context recomputed in every pass",
                    "dit_fsdp": None if sharded is None else {"ranks": sharded.P, "block_weight_MB_per_rank": round(sharded.bytes_per_rank() / 1e6, 1),
-                                                             "of_MB": round(len(sharded.blocks) * sharded.full_bytes / 1e6, 1)},
+                                                             "of_MB": round(len(sharded.blocks) * sharded.full_bytes / 1e6, 1),
+                                                             "w4_unpack_scratch_MB": round(qgemm.w4_scratch_bytes(dev) / 1e6, 1)},
                    "launch": "hip graph replay of the two DiT passes + 1 fused CFG/scheduler kernel" if graphed is not None else
                              "eager launches + 1 fused CFG/scheduler kernel",
                    "rccl_ranks": dist.get_world_size() if world > 1 else 1,
@@ -414,6 +443,30 @@ def main():
         out["roofline"] = lines[0]
     if len(lines) > 1:
         out["roofline_second_kernel"] = lines[1]
+    # HBM-bound kernels of the step (north star: "HBM GB/s against gfx950 peak"): algorithmic bytes per launch (what the wrapper
+    # hands over: rows x cols x (input + output element sizes) + the per-token vectors / the rotary table) / the launch's
+    # duration between its own HIP events, against the 8 TB/s spec
+    hb = []
+    names = {"gelu_quant_sum": "quant_rows_wave_kernel<BF16,18,GELU> (GELU + per-token quantise of the FFN hidden)",
+             "quant_sum": "rowwise_kernel<..., false> (per-token quantise: attention output -> o, cross-attention output)",
+             "layernorm_quant": "rowwise_kernel<..., LN> (LayerNorm + modulate + per-token quantise)",
+             "layernorm_rotate_quant_x3": "rotate_kernel<12,1,4,LN,MULTI> (LayerNorm + modulate + ViDiT scale / rotate + quantise for q, k, v)",
+             "layernorm_rotate_quant": "rotate_kernel<..., LN> (LayerNorm + modulate + ViDiT scale / rotate + quantise, one consumer)",
+             "rotate_quant": "rotate_kernel / rotate140_kernel (ViDiT scale / rotate + quantise)",
+             "rmsnorm_rope": "rmsnorm_rope_kernel (RMSNorm + RoPE on q / k, in place)", "rmsnorm": "rmsnorm_rope_kernel (RMSNorm only: cross-attention q / k)",
+             "layernorm": "rowwise_kernel<..., LN> (LayerNorm, fp output)"}
+    for tag, ev in htimer.items():
+        secs = sum(a.elapsed_time(b) for a, b, _ in ev) * 1e-3
+        nbytes = float(sum(n for _, _, n in ev))
+        if secs > 0:
+            hb.append({"kernel": names.get(tag, tag), "entry": tag, "launches_per_step": len(ev) / args.steps, "bytes_per_launch": nbytes / len(ev),
+                       "avg_us": secs / len(ev) * 1e6, "TBps": nbytes / secs / 1e12, "frac": nbytes / secs / HBM_PEAK,
+                       "share_of_step": secs / dt_prof})
+    hb.sort(key=lambda r: -r["share_of_step"])
+    if hb:
+        out["roofline_hbm"] = hb
+    if calib_report is not None:
+        out["calibration"] = calib_report
     if rank == 0 and world == 1 and not args.no_quality:
         # deviation of the quantized DiT output from the FP (bf16-autocast) output of the same synthetic model
         t = sched.timesteps[0:1]

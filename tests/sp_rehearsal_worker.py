@@ -1,7 +1,7 @@
 """Worker for tests/test_gpu_sp_rehearsal.py: two ranks on ONE GPU rehearse the multi-GPU path of the kernel-mode model.
 
 RCCL refuses two ranks on the same device, so the process group is gloo and the three collectives the parallel module uses
-are staged through host memory (wan/distributed/rehearsal.py; the product path calls torch.distributed directly with
+are staged through host memory (tools/one_gpu_rehearsal.py; the product path calls torch.distributed directly with
 backend "nccl").  Everything else -- sequence sharding, per-rank RoPE slice, head scatter / gather around the HIP attention
 kernel on H/P heads, the final row all-gather, the cfg-parallel all-gather -- is the product code, on the HIP kernels."""
 import os
@@ -17,8 +17,8 @@ sys.path.insert(0, os.path.join(ROOT, "wan2.1-quantization_amd"))
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", init_method="env://")
-    from wan.distributed.rehearsal import stage_collectives_through_host
-    stage_collectives_through_host()
+    from wan.distributed import stage_rehearsal_collectives  # loads tools/one_gpu_rehearsal.py (scaffolding outside the package)
+    stage_rehearsal_collectives()
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
 

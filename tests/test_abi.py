@@ -4,12 +4,15 @@ reference's extension modules exposes the reference's names."""
 import ctypes
 import os
 import re
+import subprocess
+import sys
 
 import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "wanq_hip.h")
+PKG = os.path.join(ROOT, "wan2.1-quantization_amd")
 LIB = os.path.join(ROOT, "wan2.1-quantization_amd", "lib", "libwanq_hip.so")
 
 
@@ -64,7 +67,16 @@ def test_round2_entry_points_refuse_bad_arguments(lib):
     i64 = ctypes.c_int64
     buf = ctypes.create_string_buffer(256)
     p = ctypes.cast(buf, ctypes.c_void_p)
-    assert lib.wanq_abi_version() == 5
+    assert lib.wanq_abi_version() == 6
+    # the narrow-range quantiser (ABI 6): int8 codes hold at most 127 levels, the floor is not negative
+    lib.wanq_quant_rows_levels.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                           i64, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
+    rc = lib.wanq_quant_rows_levels(p, 2, p, p, None, 2, i64(4), 64, 128, 1e-6, None)
+    assert rc == 1 and b"n_levels=128" in lib.wanq_last_error()
+    rc = lib.wanq_quant_rows_levels(p, 2, p, p, None, 2, i64(4), 64, 31, -1.0, None)
+    assert rc == 1 and b"floor" in lib.wanq_last_error()
+    rc = lib.wanq_quant_rows_levels(p, 2, p, p, None, 2, i64(4), 60, 31, 0.0, None)
+    assert rc == 2 and b"cols=60" in lib.wanq_last_error()
     # W4A8: K must hold whole 32-code groups
     rc = lib.wanq_gemm_w4a8(p, p, p, 0, p, None, 0, p, None, 0, None, 0, None, None, 0, i64(8), 16, 48, None)
     assert rc == 2 and b"K=48" in lib.wanq_last_error()
@@ -134,3 +146,39 @@ def test_gemm_kernel_selection_is_a_host_side_setting(lib):
     assert lib.wanq_gemm_select_kernel(1) == 2
     assert lib.wanq_gemm_select_kernel(7) == -1 and lib.wanq_gemm_select_kernel(-1) == -1
     assert lib.wanq_gemm_select_kernel(prev) == 1
+
+
+def test_rehearsal_switch_is_refused_unless_exactly_one_gpu_is_visible(monkeypatch, capsys):
+    """The one-GPU rehearsal (gloo + host-staged collectives, tools/one_gpu_rehearsal.py) cannot be tripped on a box that is not a
+    one-GPU box: this container shows 0 GPUs, a real node 8 -- both are refused with exit status 4 and one line."""
+    import torch
+    from wan.distributed import enter_one_gpu_rehearsal
+
+    monkeypatch.delenv("WANQ_REHEARSE_ON_ONE_GPU", raising=False)
+    assert enter_one_gpu_rehearsal("WANQ_REHEARSE_ON_ONE_GPU", 2) is False       # not requested
+    monkeypatch.setenv("WANQ_REHEARSE_ON_ONE_GPU", "1")
+    assert enter_one_gpu_rehearsal("WANQ_REHEARSE_ON_ONE_GPU", 1) is False       # a single rank has nothing to rehearse
+    for n in (0, 8):
+        monkeypatch.setattr(torch.cuda, "device_count", lambda n=n: n)
+        with pytest.raises(SystemExit) as ex:
+            enter_one_gpu_rehearsal("WANQ_REHEARSE_ON_ONE_GPU", 2)
+        assert ex.value.code == 4 and f"shows {n} GPUs: refused" in capsys.readouterr().err
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    assert enter_one_gpu_rehearsal("WANQ_REHEARSE_ON_ONE_GPU", 2) is True
+    assert "ONE-GPU REHEARSAL" in capsys.readouterr().err
+    # the scaffolding itself lives outside the product package
+    assert not os.path.exists(os.path.join(PKG, "wan", "distributed", "rehearsal.py"))
+    assert os.path.exists(os.path.join(ROOT, "tools", "one_gpu_rehearsal.py"))
+
+
+def test_wanq_lib_override_is_confined_to_the_package_lib_directory(tmp_path):
+    """WANQ_LIB (whole-step A/B runs of kernel variants) loads files under wan2.1-quantization_amd/lib/ only; any other path is an
+    ImportError, not a warning."""
+    code = "import sys; sys.path.insert(0, %r); import viditq_extension._C" % PKG
+    foreign = tmp_path / "libwanq_hip.so"
+    foreign.write_bytes(b"")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, WANQ_LIB=str(foreign)), capture_output=True, text=True)
+    assert r.returncode != 0 and "refused" in r.stderr
+    r = subprocess.run([sys.executable, "-W", "always", "-c", code], env=dict(os.environ, WANQ_LIB=os.path.join(PKG, "lib", "libwanq_hip.so")),
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "WANQ_LIB overrides" in r.stderr

@@ -2,8 +2,11 @@
 
 RCCL refuses two ranks on the same device, so a rehearsal runs its ranks over a gloo process group and stages the three
 collectives `wan.distributed.parallel` uses (all_to_all_single, all_gather_into_tensor, all_gather) through host memory.
-Used by `bench.py` under WANQ_BENCH_REHEARSE_ON_ONE_GPU=1 and by tests/sp_rehearsal_worker.py; never a measurement and
-never on the product path (one process per GPU calls torch.distributed with backend "nccl" = RCCL directly)."""
+TEST / REHEARSAL SCAFFOLDING, deliberately outside the product package (wan2.1-quantization_amd/): tests/sp_rehearsal_worker.py
+loads it directly, and the entry points (`wan/cli.py`, `bench.py`) load it by path through
+`wan.distributed.enter_one_gpu_rehearsal` only when WANQ_REHEARSE_ON_ONE_GPU=1 / WANQ_BENCH_REHEARSE_ON_ONE_GPU=1 is set AND the
+box has exactly ONE visible GPU -- on a real multi-GPU node the switch is refused with a non-zero exit.  Never a measurement and
+never the product path (one process per GPU calls torch.distributed with backend "nccl" = RCCL directly)."""
 import torch
 import torch.distributed as dist
 

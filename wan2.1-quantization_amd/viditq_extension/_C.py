@@ -9,8 +9,19 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# WANQ_LIB: another build of the same library (lib/variants/*.so from tools/probes/attn_variants_build.sh), for whole-step A/B runs
-LIB_PATH = os.environ.get("WANQ_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libwanq_hip.so")
+# WANQ_LIB: another build of the same library, for whole-step A/B runs of kernel variants.  Honoured ONLY for a file inside this
+# package's own lib/ directory (lib/variants/*.so from tools/probes/attn_variants_build.sh) -- any other path is refused, so that a
+# stray environment variable cannot make the product load a foreign binary -- and announced with a warning.
+_LIBDIR = os.path.join(os.path.dirname(_HERE), "lib")
+LIB_PATH = os.path.join(_LIBDIR, "libwanq_hip.so")
+if os.environ.get("WANQ_LIB"):
+    import warnings
+
+    _over = os.path.realpath(os.environ["WANQ_LIB"])
+    if os.path.commonpath([_over, os.path.realpath(_LIBDIR)]) != os.path.realpath(_LIBDIR):
+        raise ImportError(f"WANQ_LIB={os.environ['WANQ_LIB']} is outside {_LIBDIR}: refused (the override exists for A/B builds under lib/variants/ only)")
+    LIB_PATH = _over
+    warnings.warn(f"WANQ_LIB overrides the hot-path library: loading {LIB_PATH} (A/B and diagnostic builds only)", RuntimeWarning)
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -18,10 +29,6 @@ if not os.path.exists(LIB_PATH):
         f"`python wan2.1-quantization_amd/build.py` (hipcc --offload-arch=gfx950). "
         "There is no CPU or PyTorch fallback for the quantized hot path.")
 
-if os.environ.get("WANQ_LIB"):
-    import warnings
-
-    warnings.warn(f"WANQ_LIB overrides the hot-path library: loading {LIB_PATH} (A/B and diagnostic builds only)", RuntimeWarning)
 lib = ctypes.CDLL(LIB_PATH)
 
 F16, BF16, F32, I32, I16 = 0, 1, 2, 3, 4
@@ -101,10 +108,27 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def call(name, *args):
+_call_timer = None
+
+
+def set_call_timer(t):
+    """bench.py hook: when set to a dict, every launch whose wrapper states its algorithmic HBM bytes (`hbm=(tag, bytes)`) appends
+    (start_event, end_event, bytes) to t[tag], the events bracketing exactly that launch on the current stream."""
+    global _call_timer
+    _call_timer = t
+
+
+def call(name, *args, hbm=None):
+    timed = _call_timer is not None and hbm is not None
+    if timed:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(lib.wanq_last_error().decode() or f"{name} failed with code {rc}")
+    if timed:
+        e.record()
+        _call_timer.setdefault(hbm[0], []).append((s, e, int(hbm[1])))
 
 
 # --- argument checks in the spirit of the reference's TORCH_CHECK macros (K/csrc/utils.cuh:4-22):

@@ -42,7 +42,8 @@ def _quant_rows(input, sum_output, scaling, act, static_amax):
     out = torch.empty(input.shape, dtype=torch.int8, device=input.device)
     with torch.cuda.device(input.device):
         _C.call("wanq_quant_rows", _C.ptr(input), _C.dt(input), _C.ptr(out), _C.ptr(scaling), _C.ptr(sum_output),
-                _C.dt(scaling), rows, cols, act, static_amax, _C.stream())
+                _C.dt(scaling), rows, cols, act, static_amax, _C.stream(),
+                hbm=("gelu_quant_sum" if act else "quant_sum", rows * cols * (input.element_size() + 1) + 2 * rows * scaling.element_size()))
     return out
 
 
@@ -133,7 +134,8 @@ def _layernorm(output, input, weight, shift_msa, scale_msa, sum_output, scaling,
     with torch.cuda.device(input.device):
         _C.call("wanq_layernorm_rows", _C.ptr(input), _C.dt(input), _C.ptr(weight), _C.ptr(shift_msa), _C.ptr(scale_msa),
                 mod_dtype, mod_stride, rows // batch, float(epsilon), out_fp, out_dt, q, scale_p, sum_p, vec_dt,
-                rows, cols, _C.stream())
+                rows, cols, _C.stream(),
+                hbm=("layernorm_quant" if quant else "layernorm", rows * cols * (input.element_size() + output.element_size()) + 8 * rows * bool(quant)))
 
 
 def layernorm_nobias(out, input, weight, epsilon):
@@ -201,7 +203,8 @@ def col_absmax_(running_max, x):
     _C.check_shape("running_max", running_max, cols)
     _C.check_same_device(x, running_max)
     with torch.cuda.device(x.device):
-        _C.call("wanq_col_absmax", _C.ptr(x), _C.dt(x), _C.ptr(running_max), rows, cols, _C.stream())
+        _C.call("wanq_col_absmax", _C.ptr(x), _C.dt(x), _C.ptr(running_max), rows, cols, _C.stream(),
+                hbm=("col_absmax", rows * cols * x.element_size() + 4 * cols))
     return running_max
 
 
@@ -290,7 +293,8 @@ def rotate_quant(input, premul, rotation, sum_output, scaling, out_fp=None, quan
         _C.call("wanq_rotate_quant_rows", _C.ptr(input), _C.dt(input), _C.ptr(premul), had_k,
                 _C.ptr(out_fp), _C.dt(out_fp) if out_fp is not None else _C.F32, _C.ptr(q),
                 _C.ptr(scaling) if quantize else None, _C.ptr(sum_output) if quantize else None,
-                _C.dt(scaling) if quantize else _C.F32, rows, cols, _C.stream())
+                _C.dt(scaling) if quantize else _C.F32, rows, cols, _C.stream(),
+                hbm=("rotate_quant", rows * cols * (input.element_size() + bool(quantize) + (out_fp.element_size() if out_fp is not None else 0))))
     return q
 
 
@@ -322,7 +326,8 @@ def layernorm_rotate_quant(output, input, weight, shift_msa, scale_msa, premul, 
     with torch.cuda.device(input.device):
         _C.call("wanq_layernorm_rotate_quant_rows", _C.ptr(input), _C.dt(input), _C.ptr(weight), _C.ptr(shift_msa),
                 _C.ptr(scale_msa), _C.F32, mod_stride, rows // batch, float(epsilon), _C.ptr(premul), had_k,
-                _C.ptr(output), _C.ptr(scaling), _C.ptr(sum_output), _C.dt(scaling), rows, cols, _C.stream())
+                _C.ptr(output), _C.ptr(scaling), _C.ptr(sum_output), _C.dt(scaling), rows, cols, _C.stream(),
+                hbm=("layernorm_rotate_quant", rows * cols * (input.element_size() + 1) + 8 * rows))
 
 
 def layernorm_rotate_quant_multi(outputs, input, weight, shift_msa, scale_msa, premuls, rotation, sum_outputs, scalings, epsilon):
@@ -363,6 +368,6 @@ def layernorm_rotate_quant_multi(outputs, input, weight, shift_msa, scale_msa, p
         _C.call("wanq_layernorm_rotate_quant_rows_multi", _C.ptr(input), _C.dt(input), _C.ptr(weight), _C.ptr(shift_msa),
                 _C.ptr(scale_msa), _C.F32, mod_stride, rows // batch, float(epsilon), n, _C.ptr_array(premuls),
                 had_k, _C.ptr_array(outputs), _C.ptr_array(scalings), _C.ptr_array(sum_outputs), _C.dt(scalings[0]), rows, cols,
-                _C.stream())
+                _C.stream(), hbm=(f"layernorm_rotate_quant_x{n}", rows * cols * (input.element_size() + n) + 8 * rows * n))
     return outputs
 

@@ -107,7 +107,7 @@ def w8a8_linear(input, weight, scale_input, scale_weight, bias=None, input_sum=N
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         if w4 and _W4_UNPACK_ROWS and M >= _W4_UNPACK_ROWS and K % 128 == 0 and K >= 256:
-            weight, w4 = unpack_w4(weight, bias=0), False  # inside the timed region: part of this product's cost
+            weight, w4 = unpack_w4(weight, bias=0, out=_w4_scratch_for(weight)), False  # inside the timed region: part of this product's cost
         _C.call("wanq_gemm_w4a8" if w4 else "wanq_gemm_w8a8", _C.ptr(input), _C.ptr(weight), _C.ptr(out), _C.dt(out_dtype), _C.ptr(scale_input),
                 _C.ptr(input_sum), _C.dt(scale_input), _C.ptr(scale_weight), _C.ptr(bias), _C.dt(scale_weight),
                 _C.ptr(zp_weight), _C.dt(zp_weight) if zp_weight is not None else _C.F32, _C.ptr(gate),
@@ -160,13 +160,36 @@ def pack_w4(codes, bias=8):
     return out
 
 
-def unpack_w4(packed, bias=8):
-    """uint8 [N, K/2] -> int8 codes [N, K]."""
+_w4_scratch = {}
+
+
+def _w4_scratch_for(packed):
+    """ONE int8 [N, K] buffer per (device, stream, N, K) for the large-M W4A8 path (a fresh 70-MB tensor per launch at the
+    14B FFN shapes was twice the packed weights' footprint and invisible to the memory accounting).  Launches on one stream are
+    ordered, so the GEMM that reads the expansion is enqueued before the next expansion that overwrites it."""
+    N, K2 = packed.shape
+    key = (packed.device, torch.cuda.current_stream(packed.device).cuda_stream, N, K2 * 2)
+    buf = _w4_scratch.get(key)
+    if buf is None:
+        buf = _w4_scratch[key] = torch.empty((N, K2 * 2), dtype=torch.int8, device=packed.device)
+    return buf
+
+
+def w4_scratch_bytes(device=None):
+    """Bytes held by the large-M W4A8 path's expansion buffers (reported beside the sharded weights by bench.py / --dit_fsdp)."""
+    return sum(b.numel() for k, b in _w4_scratch.items() if device is None or k[0] == torch.device(device))
+
+
+def unpack_w4(packed, bias=8, out=None):
+    """uint8 [N, K/2] -> int8 codes [N, K] (into `out` when given)."""
     _C.check_gpu("packed", packed)
     _C.check_contig("packed", packed)
     _C.check_dtype("packed", packed, torch.uint8)
     N, K2 = packed.shape
-    out = torch.empty((N, K2 * 2), dtype=torch.int8, device=packed.device)
+    if out is None:
+        out = torch.empty((N, K2 * 2), dtype=torch.int8, device=packed.device)
+    else:
+        _check_i8("out", out, N, K2 * 2)
     with torch.cuda.device(packed.device):
         _C.call("wanq_unpack_w4", _C.ptr(packed), _C.ptr(out), int(bias), N, K2 * 2, _C.stream())
     return out

@@ -82,15 +82,17 @@ def setup_distributed(args, num_heads):
 
     rank, world, local = int(os.getenv("RANK", 0)), int(os.getenv("WORLD_SIZE", 1)), int(os.getenv("LOCAL_RANK", 0))
     # Rehearsal of the multi-rank control flow on a ONE-GPU box (RCCL refuses two ranks on one device): every rank uses cuda:0,
-    # the rendezvous is gloo and the collectives are staged through host memory (wan/distributed/rehearsal.py).  Never a product mode.
-    rehearse = world > 1 and os.getenv("WANQ_REHEARSE_ON_ONE_GPU") == "1"
+    # the rendezvous is gloo and the collectives are staged through host memory (tools/one_gpu_rehearsal.py: test scaffolding
+    # outside this package).  Refused with a non-zero exit on a box with more than one GPU; never a product mode.
+    from .distributed import enter_one_gpu_rehearsal, stage_rehearsal_collectives
+
+    rehearse = enter_one_gpu_rehearsal("WANQ_REHEARSE_ON_ONE_GPU", world)
     if rehearse:
         local = 0
     torch.cuda.set_device(local)
     if rehearse:
         dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
-        from .distributed.rehearsal import stage_collectives_through_host
-        stage_collectives_through_host()
+        stage_rehearsal_collectives()
     elif world > 1:
         dist.init_process_group(backend="nccl", init_method="env://", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local))

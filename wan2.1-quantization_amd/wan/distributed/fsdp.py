@@ -42,18 +42,26 @@ class ShardedBlocks:
         self.blocks, self.group, self.slots_fn = list(blocks), group, slots_fn
         self.P = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.P > 1 else 0
-        # A communicator of its own for the weight gathers, so that they do not queue behind the Ulysses all-to-alls of the block
-        # being computed.  dist.new_group is collective over WORLD, so it is only created implicitly when `group` IS the world
-        # (every rank builds its ShardedBlocks at the same point, as bench.py / quant_generate.py do); a proper subgroup must
-        # bring its own `gather_group` (or gets the shared one).  WANQ_FSDP_SHARED_GROUP=1 keeps the gathers on `group` itself:
-        # the two-communicator overlap has never run on real multi-rank RCCL from here, this is the fallback switch.
+        # Which communicator carries the weight gathers.  DEFAULT: the sharding group itself (`group`) -- ProcessGroupNCCL then runs a
+        # block's gather and its Ulysses all-to-alls on one stream, in issue order: correct, the gather of block i+1 simply queues
+        # behind what was issued before it.  WANQ_FSDP_SHARED_GROUP=0 opts in to a communicator of their own (so that they do not
+        # queue behind the all-to-alls of the block being computed): that two-communicator overlap has never run on real
+        # multi-rank RCCL from here, so it is not the default until it has.  dist.new_group is
+        # collective over WORLD, so the separate group is only created implicitly when `group` IS the world (every rank builds its
+        # ShardedBlocks at the same point, as bench.py / quant_generate.py do); a proper subgroup must bring its own `gather_group`.
+        import logging
         import os
 
-        if self.P > 1 and gather_group is None and os.environ.get("WANQ_FSDP_SHARED_GROUP", "0") != "1":
+        if self.P > 1 and gather_group is None and os.environ.get("WANQ_FSDP_SHARED_GROUP", "1") == "0":
             is_world = group is None or group is dist.group.WORLD or dist.get_world_size(group) == dist.get_world_size()
             if is_world:
                 gather_group = dist.new_group(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD))
-        self.gather_group = gather_group if (self.P > 1 and gather_group is not None) else group
+        own = self.P > 1 and gather_group is not None
+        self.gather_group = gather_group if own else group
+        if self.P > 1 and self.rank == 0:
+            logging.getLogger(__name__).info(
+                "dit_fsdp: weight gathers on %s", "a communicator of their own (WANQ_FSDP_SHARED_GROUP=0 or gather_group given)" if own
+                else "the sharding group (shared with the Ulysses exchange; WANQ_FSDP_SHARED_GROUP=0 selects a separate one)")
         first = slots_fn(self.blocks[0])
         self.layout = []  # (byte offset, nbytes, shape, dtype) per slot
         off = 0

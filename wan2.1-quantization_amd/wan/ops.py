@@ -25,7 +25,9 @@ def rmsnorm_rope_(x, weight, rope, head_dim, rows_per_batch=None, eps=1e-6, out=
     out = x if out is None else out
     with torch.cuda.device(x.device):
         _C.call("wanq_rmsnorm_rope", _C.ptr(x), _C.dt(x), _C.ptr(weight), _C.ptr(rope), _C.ptr(out), _C.dt(out), rows, cols,
-                head_dim, rows_per_batch or rows, positions, float(eps), _C.stream())
+                head_dim, rows_per_batch or rows, positions, float(eps), _C.stream(),
+                hbm=("rmsnorm_rope" if rope is not None else "rmsnorm", rows * cols * (x.element_size() + out.element_size()) +
+                     (min(rows, positions) * head_dim * 4 if rope is not None else 0)))
     return out
 
 

@@ -135,6 +135,17 @@ class QuantWanModel(WanModel, QuantModel):
                         f"{key}.attn_map.group = {am.get('group')!r}: the 'block' mode of the reference is tied to CogVideoX's 13x30x45 grid "
                         "and to per-head reorder tables (Q/base/quant_attn.py:176-236); 'row' is implemented (streamed, csrc/attn_map.hip)")
                 amap[key] = (int(am.get("n_bits", 8)), bool(am.get("sym", False)))
+        # the fp32 ends of a pass (csrc/embed_head.hip: patch / time / text embeddings, head) read these parameters as fp32, as the
+        # reference computes them (amp.autocast(dtype=torch.float32) around the time MLPs and the head, model.py:592-597,396-399):
+        # say so here, once, instead of a dtype refusal from inside the first forward
+        ends = [("patch_embedding", self.patch_embedding), ("time_embedding.0", self.time_embedding[0]), ("time_embedding.2", self.time_embedding[2]),
+                ("time_projection.1", self.time_projection[1]), ("text_embedding.0", self.text_embedding[0]), ("text_embedding.2", self.text_embedding[2]),
+                ("head.head", self.head.head)]
+        bad = [f"{n}.weight is {m.weight.dtype}" for n, m in ends if m.weight.dtype != torch.float32]
+        if bad or self.head.modulation.dtype != torch.float32:
+            raise TypeError("kernel mode keeps the embeddings and the head in fp32 (load the checkpoint in fp32, or call .float() on them "
+                            "before hardware_forward_refactor): " + ", ".join(bad + ([f"head.modulation is {self.head.modulation.dtype}"]
+                                                                                   if self.head.modulation.dtype != torch.float32 else [])))
         self.__dict__.pop("_ctx_cache", None)
         self.hip_blocks = nn.ModuleList([WanAttentionBlockWithHipKernel.from_float(
             b, None, False, act_dtype, attn_qk8=qk8.get("attn", False), cross_attn_qk8=qk8.get("cross_attn", False),
@@ -225,6 +236,10 @@ class QuantWanModel(WanModel, QuantModel):
     def _modulations(self, device):
         """All kernel-mode blocks' modulation tables as one [blocks, 6, C] tensor (so that `modulation + e0` of reference
         model.py:322-324 is one launch per pass, not one per block); rebuilt when a block's table was written or moved."""
+        if torch.cuda.is_current_stream_capturing():
+            # under graph capture the table must live in the graph's own memory pool: a tensor this cache owns would be freed by the
+            # next rebuild (a modulation write, .to(), hardware_forward_refactor) while the captured graph still points at it (ADVICE r4)
+            return torch.cat([hb.modulation.to(device) for hb in self.hip_blocks]).contiguous()
         key = (device, tuple(hb.modulation._version for hb in self.hip_blocks), tuple(hb.modulation.data_ptr() for hb in self.hip_blocks))
         ent = self.__dict__.get("_mod_all")
         if ent is None or ent[0] != key:
