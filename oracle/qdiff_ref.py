@@ -208,13 +208,19 @@ def paley1(q):
 _PALEY = {12: 11, 20: 19, 60: 59, 108: 107, 140: 139}
 
 
-def had_k(n):
+def had_k(n, strict=True):
     """get_hadK: pick the non-power-of-two factor K and its table.  Q/quarot/quarot_utils.py:100-155.
-    Same precedence order as the reference; tables we cannot construct raise NotImplementedError,
-    sizes the reference itself rejects raise AssertionError (e.g. 13824)."""
+    Same precedence order as the reference; tables we cannot construct raise NotImplementedError.
+    strict (the reference): the FIRST K that divides n must leave a power-of-two co-factor, else AssertionError -- 13824 = 144 x 96
+    dies at :110-112 although its K = 108 branch (:118-121) would fit.
+    strict=False (REPO-DEFINED, not the reference): a K whose co-factor is not a power of two is skipped and the reference's own
+    order continues: 13824 -> K = 108 (Paley-107, the reference's get_had108 table) x H_128.  Sizes the reference accepts are
+    unaffected.  Pinned by tests/golden/a5_hadamard_13824.npz (made with the reference's table and butterfly)."""
     for K in (172, 156, 144, 140, 108, 60, 52, 36, 28, 40, 20, 12):
         if n % K == 0:
-            assert _is_pow2(n // K), f"{n} = {K} x non-power-of-two"
+            if not _is_pow2(n // K):
+                assert not strict, f"{n} = {K} x non-power-of-two"
+                continue
             if K in _PALEY:
                 return paley1(_PALEY[K]), K
             if K == 40:  # the reference's had40 equals [[H20,H20],[H20,-H20]]
@@ -224,14 +230,14 @@ def had_k(n):
     return None, 1
 
 
-def matmul_hadU(X):
-    """(hadK (x) H_{n/K}) X / sqrt(n) along the last axis.  Q/quarot/quarot_utils.py:158-179.
+def matmul_hadU(X, strict=True):
+    """(hadK (x) H_{n/K}) X / sqrt(n) along the last axis.  Q/quarot/quarot_utils.py:158-179.  strict: see had_k.
 
     The reference's butterfly loop is the natural-order Walsh-Hadamard transform on each of the K
     contiguous blocks, followed by hadK across blocks; the divisor is fp32 sqrt (`torch.tensor(n).sqrt()`)."""
     X = np.asarray(X)
     n = X.shape[-1]
-    hadK, K = had_k(n)
+    hadK, K = had_k(n, strict)
     m = n // K
     v = X.reshape(-1, K, m).astype(X.dtype, copy=True)
     h = 1

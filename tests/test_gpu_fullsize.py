@@ -613,6 +613,41 @@ def test_rotate_8960_full_size_sampled_rows():
     assert d.max() <= 1 and (d != 0).mean() < 2e-3, (d.max(), (d != 0).mean())
 
 
+def test_rotate_13824_config4_per_rank_size_sampled_rows():
+    """The 13824-column transform (rotate108_kernel: the 14B ffn.2 input; repo-defined, the reference asserts on this width) at the
+    per-rank size of BASELINE configs 4 / 5, [9450, 13824] bf16: row invariants over the whole output, sampled rows against the
+    oracle's H_108 (x) H_128 evaluated in float64."""
+    import viditq_extension.fused as fused
+    from oracle import qdiff_ref as qr
+    from qdiff.quarot import quarot_utils as qu
+
+    R, N = 9450, 13824
+    g = torch.Generator(device=DEV).manual_seed(108)
+    x = (torch.randn(R, N, device=DEV, generator=g) * torch.exp(0.7 * torch.randn(N, device=DEV, generator=g))).clamp_min(-0.17).to(torch.bfloat16)
+    x[5] = 0
+    pm = (torch.rand(N, device=DEV, generator=g) + 0.5) * (torch.randint(0, 2, (N,), device=DEV, generator=g) * 2 - 1).float()
+    rot = qu.kernel_rotation_params(N, DEV)
+    assert rot[0] == 108
+    scale, ssum = torch.zeros(R, device=DEV), torch.zeros(R, device=DEV)
+    q = fused.rotate_quant(x, pm, rot, ssum, scale)
+    qi = q.to(torch.int32)
+    live = torch.ones(R, dtype=torch.bool, device=DEV)
+    live[5] = False
+    assert bool((qi.abs().amax(1)[live] == 127).all()) and int(qi[5].abs().max()) == 0 and scale[5].item() == pytest.approx(1e-6)
+    np.testing.assert_allclose(ssum.cpu().numpy(), qi.sum(1).cpu().numpy().astype(np.float64) * scale.cpu().numpy().astype(np.float64), rtol=1e-6, atol=1e-6)
+    rows = np.unique(np.concatenate([np.random.default_rng(108).integers(0, R, 24), [0, 4, 5, 6, R - 1]]))
+    ref = qr.matmul_hadU(x[rows].double().cpu().numpy() * pm.double().cpu().numpy(), strict=False).astype(np.float32)
+    oq, oscale = qr.dynamic_quantize_sym(ref)
+    np.testing.assert_allclose(scale[rows].cpu().numpy(), oscale, rtol=2e-6)
+    d = np.abs(q[rows].cpu().numpy().astype(np.int32) - oq)
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3, (d.max(), (d != 0).mean())
+    # orthogonality at full size: the transform preserves every row's norm (fp output, all rows)
+    out = torch.empty(R, N, device=DEV)
+    fused.rotate_quant(x, None, rot, None, None, out_fp=out, quantize=False)
+    n_in, n_out = x.float().norm(dim=1), out.norm(dim=1)
+    assert float(((n_out - n_in).abs() / n_in.clamp_min(1e-6))[live].max()) < 2e-5
+
+
 @pytest.mark.parametrize("solver", ["unipc", "dpm++", "euler"])
 def test_fused_step_full_latent_equals_plain_scheduler(solver):
     """CFG combine + scheduler update as one kernel on the headline latent [16, 21, 60, 104], 30 steps, against the plain

@@ -22,9 +22,10 @@ def cfg(**extra):
     return qcfg.create(dict({"weight": {"n_bits": 8, "sym": False}, "act": {"n_bits": 8, "sym": True}}, **extra))
 
 
-@pytest.mark.parametrize("n", [1536, 5120, 8960])
+@pytest.mark.parametrize("n", [1536, 5120, 8960, 13824])
 def test_rotation_kernel_vs_reference_hadamard_products(golden, n):
-    """out_fp of wanq_rotate_quant_rows == hadU(x) of the reference (golden a5), fp32 vs fp64: 1e-5."""
+    """out_fp of wanq_rotate_quant_rows == hadU(x) of the reference (golden a5), fp32 vs fp64: 1e-5.  (13824: repo-defined K = 108 --
+    the fixture is made from the reference's own get_had108 table and butterfly, tests/golden/make_golden_had108.py.)"""
     import viditq_extension.fused as fused
     from qdiff.quarot import quarot_utils as qu
 
@@ -37,7 +38,7 @@ def test_rotation_kernel_vs_reference_hadamard_products(golden, n):
     # with a sign pre-multiplier it is x @ R
     s = t(g["signs"], torch.float32)
     fused.rotate_quant(x, s, rot, None, None, out_fp=out, quantize=False)
-    ref = qr.matmul_hadU(g["x"] * g["signs"])
+    ref = qr.matmul_hadU(g["x"].astype(np.float64) * g["signs"], strict=False)
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=2e-5)
 
 
@@ -614,3 +615,68 @@ def test_viditq_linear_with_asymmetric_or_narrow_activations_vs_oracle(golden, a
     step = np.abs(xt).max(axis=1).max() / (2 ** (bits - 1))   # one activation step
     assert np.abs(y - want).max() < 0.02 * step * np.abs(g["w_final"]).sum(axis=1).max() + 1e-3
     assert np.linalg.norm(y - want) / np.linalg.norm(want) < 2e-3
+
+
+def test_rotate_13824_dtypes_outputs_and_viditq_layer():
+    """n = 13824 = 108 x 128, the 14B ffn.2 input (csrc/rotate108.hip; REPO-DEFINED: the reference asserts on this width):
+    bf16 / fp16 / fp32 input, fp output in every dtype, codes / scales / sums against the oracle's H_108 (x) H_128 in float64, the
+    eps row; then the width as a ViDiT layer (mask, double-quantised rotated weight, forward) against the oracle."""
+    import viditq_extension.fused as fused
+    from qdiff.quarot import quarot_utils as qu
+    from qdiff.viditq.viditq_quant_layer import ViDiTQuantizedLinear
+
+    n, rows = 13824, 67
+    g = torch.Generator().manual_seed(13824)
+    x = (torch.randn(rows, n, generator=g) * torch.exp(0.7 * torch.randn(n, generator=g))).clamp_min(-0.17)  # GELU-like
+    x[5] = 0
+    pm = (torch.rand(n, generator=g) + 0.5) * (torch.randint(0, 2, (n,), generator=g) * 2 - 1)
+    rot = qu.kernel_rotation_params(n, DEV)
+    assert rot[0] == 108
+    for dt in (torch.bfloat16, torch.float16, torch.float32):
+        xd = x.to(dt)
+        ref = qr.matmul_hadU(xd.double().numpy() * pm.double().numpy(), strict=False)
+        oq, oscale = qr.dynamic_quantize_sym(ref.astype(np.float32))
+        scale, ssum = torch.zeros(rows, device=DEV), torch.zeros(rows, device=DEV)
+        out = torch.empty(rows, n, device=DEV)
+        q = fused.rotate_quant(xd.to(DEV), pm.to(DEV), rot, ssum, scale, out_fp=out)
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=3e-6 * np.abs(ref).max())
+        np.testing.assert_allclose(scale.cpu().numpy(), oscale, rtol=2e-6)
+        d = np.abs(q.cpu().numpy().astype(np.int32) - oq)
+        assert d.max() <= 1 and (d != 0).mean() < 2e-3
+        np.testing.assert_allclose(ssum.cpu().numpy(), q.cpu().numpy().astype(np.int64).sum(1) * scale.cpu().numpy().astype(np.float64),
+                                   rtol=1e-6, atol=1e-6)
+        assert scale[5].item() == pytest.approx(1e-6) and int(q[5].abs().max()) == 0
+    for odt in (torch.bfloat16, torch.float16):
+        out = torch.empty(rows, n, dtype=odt, device=DEV)
+        s16, m16 = torch.zeros(rows, dtype=torch.float16, device=DEV), torch.zeros(rows, dtype=torch.float16, device=DEV)
+        fused.rotate_quant(x.to(DEV), pm.to(DEV), rot, m16, s16, out_fp=out)
+        ref = qr.matmul_hadU(x.double().numpy() * pm.double().numpy(), strict=False)
+        np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=2 ** -8, atol=1e-6)
+    with pytest.raises(RuntimeError, match="13824"):  # no LayerNorm form at this width (no model dimension is 13824)
+        fused.layernorm_rotate_quant(torch.empty(4, n, dtype=torch.int8, device=DEV), x[:4].to(DEV), None, None, None, pm.to(DEV), rot,
+                                     torch.zeros(4, device=DEV), torch.zeros(4, device=DEV), 1e-6)
+    # ---- the layer
+    out_f, rows = 40, 21
+    w = torch.randn(out_f, n, generator=g) * 0.02 * torch.exp(0.5 * torch.randn(n, generator=g))
+    b = torch.randn(out_f, generator=g) * 0.1
+    x = torch.randn(rows, n, generator=g) * torch.exp(0.8 * torch.randn(n, generator=g))
+    act_mask = x.abs().amax(0).clamp_min(1e-3)
+    signs = (torch.randint(0, 2, (n,), generator=g) * 2 - 1).double()
+    lin = torch.nn.Linear(n, out_f).to(DEV)
+    lin.weight.data, lin.bias.data = w.to(DEV), b.to(DEV)
+    vl = ViDiTQuantizedLinear(n, out_f, True, DEV, cfg(viditq={"alpha": 0.5665, "layer_name_regex": ""}), lin)
+    mask = qr.vidit_channel_mask(w.numpy(), act_mask.numpy(), 0.5665)
+    vl.channel_mask = torch.from_numpy(mask).to(DEV)
+    vl.rotation_signs = signs
+    vl.update_quantized_weight_rotated_and_scaled()
+    w1, _, _ = qr.static_fake_quant((w.numpy() / mask[None, :]).astype(np.float32), 8, False)
+    w2in = qr.matmul_hadU(w1.astype(np.float64) * signs.numpy()[None, :], strict=False).astype(np.float32)
+    w2, d2, z2 = qr.static_fake_quant(w2in, 8, False)
+    np.testing.assert_allclose(vl.w_quantizer.delta.reshape(-1).cpu().numpy(), d2.reshape(-1), rtol=2e-6)
+    dw = np.abs(vl.weight.data.cpu().numpy() - w2) / d2.reshape(-1, 1)
+    assert dw.max() <= 1.0 + 1e-3 and (dw > 0.5).mean() < 2e-3
+    xt = qr.matmul_hadU((x.numpy() * mask[None, :]).astype(np.float32).astype(np.float64) * signs.numpy()[None, :], strict=False).astype(np.float32)
+    xq, xs = qr.dynamic_quantize_sym(xt)
+    y_ref = (xq.astype(np.float64) * xs[:, None]) @ w2.astype(np.float64).T + b.numpy()
+    y = vl(x.to(DEV))
+    assert np.abs(y.cpu().numpy() - y_ref).max() < 5e-3 * np.abs(y_ref).max() + 1e-3

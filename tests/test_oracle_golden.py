@@ -92,6 +92,28 @@ def test_a5_unsupported_sizes():
         qr.had_k(13824)
 
 
+def test_a5_hadamard_13824_repo_defined_from_the_references_table(golden):
+    """13824 columns (14B ffn.2): the reference's precedence asserts at K = 144 before reaching its K = 108 branch.  strict=False
+    skips the non-power-of-two co-factor and lands on the reference's own get_had108 table x H_128 -- REPO-DEFINED behaviour,
+    pinned by products of the reference's table and butterfly (tests/golden/make_golden_had108.py)."""
+    g = golden("a5_hadamard_13824")
+    H, K = qr.had_k(13824, strict=False)
+    assert K == 108 == int(g["K"])
+    assert np.array_equal(H[0], g["table_row0"]) and np.array_equal(H[1], g["table_row1"])       # Paley-107 IS get_had108
+    w = np.arange(1, 109)
+    assert int((H * w[:, None] * w[None, :]).sum()) == int(g["table_checksum"])
+    assert np.array_equal(H @ H.T, 108 * np.eye(108, dtype=np.int64))
+    hx = qr.matmul_hadU(g["x"].astype(np.float64), strict=False)
+    np.testing.assert_allclose(hx, g["hadU_x"], rtol=0, atol=1e-12)
+    E = np.zeros((len(g["unit_rows"]), 13824))
+    E[np.arange(len(g["unit_rows"])), g["unit_rows"]] = 1.0
+    np.testing.assert_allclose(qr.matmul_hadU(E, strict=False)[:, :256], g["hadU_units_first_col_block"], rtol=0, atol=1e-15)
+    # sizes the reference accepts are unaffected by the fall-through
+    for n in (96, 1536, 5120, 8960, 4096):
+        a, b = qr.had_k(n), qr.had_k(n, strict=False)
+        assert a[1] == b[1] and (a[0] is None or np.array_equal(a[0], b[0]))
+
+
 def test_a4_viditq_layer(golden):
     g = golden("a4_viditq")
     mask = qr.vidit_channel_mask(g["w"], g["act_mask"], 0.5665)

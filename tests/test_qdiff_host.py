@@ -57,12 +57,12 @@ def test_layer_type_selection():
     assert pick_layer_type(c, "blocks.0.ffn.0").__name__ == "SQQuantizedLinear"
 
 
-@pytest.mark.parametrize("n", [96, 1536, 5120, 8960])
+@pytest.mark.parametrize("n", [96, 1536, 5120, 8960, 13824])
 def test_torch_hadamard_matches_reference_products(golden, n):
     g = golden(f"a5_hadamard_{n}")
     _, K = qu.get_hadK(n)
     assert K == int(g["K"])
-    hx = qu.matmul_hadU(torch.from_numpy(g["x"]))
+    hx = qu.matmul_hadU(torch.from_numpy(g["x"]).double())  # (13824: repo-defined K = 108, the reference's own table; see get_hadK)
     np.testing.assert_allclose(hx.numpy(), g["hadU_x"], rtol=0, atol=1e-12)
     if "xR" in g:
         R = qu.random_hadamard_matrix(n, "cpu", torch.from_numpy(g["signs"]))
@@ -71,7 +71,11 @@ def test_torch_hadamard_matches_reference_products(golden, n):
 
 def test_hadamard_size_rules():
     with pytest.raises(AssertionError):
-        qu.get_hadK(13824)  # the reference asserts too
+        qu.get_hadK(13824, strict=True)  # the reference to the letter asserts
+    H, K = qu.get_hadK(13824)            # repo-defined: its own K = 108 branch
+    assert K == 108 and torch.equal(H @ H.T, 108 * torch.eye(108, dtype=torch.float64))
+    k, h = qu.kernel_rotation_params(13824, "cpu")  # 108 x 128: its own kernel (csrc/rotate108.hip)
+    assert k == 108 and h.shape == (108, 108)
     k, h = qu.kernel_rotation_params(8960, "cpu")  # 140 x 64: its own kernel (csrc/rotate140.hip), Paley matrix of order 140
     assert k == 140 and h.shape == (140, 140) and torch.equal(h @ h.T, 140 * torch.eye(140))
     assert qu.kernel_rotation_params(140 * 32, "cpu") is None  # any other block < 128: no fused kernel

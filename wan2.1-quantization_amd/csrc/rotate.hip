@@ -577,6 +577,10 @@ extern "C" int wanq_rotate_quant_rows(const void* x, int x_dtype, const float* p
     WANQ_REQUIRE(cols == 8960, WANQ_E_SHAPE, "%s: had_k=140 is the transform of cols=8960 (got %d)", what, cols);
     return rotate140_rows(x, x_dtype, premul, out_fp, out_dtype, q, scale, sum, vec_dtype, rows, (hipStream_t)stream, what);
   }
+  if (had_k == 108) {  // 13824 = 108 x 128 (14B ffn.2): Paley-108 on the matrix cores (rotate108.hip); repo-defined, the reference asserts
+    WANQ_REQUIRE(cols == 13824, WANQ_E_SHAPE, "%s: had_k=108 is the transform of cols=13824 (got %d)", what, cols);
+    return rotate108_rows(x, x_dtype, premul, out_fp, out_dtype, q, scale, sum, vec_dtype, rows, (hipStream_t)stream, what);
+  }
   if (int e = check_rotation(what, had_k, cols)) return e;
   if (rows == 0) return WANQ_OK;
   RotParams p{};

@@ -40,6 +40,10 @@ int premul_quant_rows(bool ln, const void* x, int x_dtype, const void* gamma, co
 int rotate140_rows(const void* x, int x_dtype, const float* premul, void* out_fp, int out_dtype, int8_t* q, void* scale, void* sum,
                    int vec_dtype, int64_t rows, hipStream_t st, const char* what);
 
+// rotate108.hip: the n = 13824 = 108 x 128 transform (+ per-token quantiser); repo-defined, see the file's header
+int rotate108_rows(const void* x, int x_dtype, const float* premul, void* out_fp, int out_dtype, int8_t* q, void* scale, void* sum,
+                   int vec_dtype, int64_t rows, hipStream_t st, const char* what);
+
 inline bool is_fp(int dt) { return dt == WANQ_F16 || dt == WANQ_BF16 || dt == WANQ_F32; }
 inline bool is_vec(int dt) { return dt == WANQ_F16 || dt == WANQ_F32; }
 

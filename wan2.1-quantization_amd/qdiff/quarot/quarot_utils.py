@@ -33,13 +33,19 @@ def sylvester(n):
 _PALEY = {12: 11, 20: 19, 60: 59, 108: 107, 140: 139}
 
 
-def get_hadK(n, transpose=False):
-    """(hadK as float64 tensor or None, K), same precedence as the reference (quarot_utils.py:100-155).
-    Sizes the reference rejects raise AssertionError (13824 = 144 x 96); tables not constructible here raise
-    NotImplementedError (orders 172, 156, 144, 52, 36, 28 -- none occurs in Wan2.1)."""
+def get_hadK(n, transpose=False, strict=False):
+    """(hadK as float64 tensor or None, K), the reference's precedence order (quarot_utils.py:100-155).  Tables not constructible
+    here raise NotImplementedError (orders 172, 156, 144, 52, 36, 28 -- none occurs in Wan2.1).
+    strict=True is the reference to the letter: the FIRST K that divides n must leave a power-of-two co-factor, else
+    AssertionError -- which makes 13824 (Wan2.1-14B ffn.2) unrotatable: 13824 % 144 == 0 trips the assert at :110-112 before the
+    K = 108 branch (:118-121) is reached, although 13824 = 108 x 128 fits it.  The default is REPO-DEFINED for exactly
+    those sizes: a K with a non-power-of-two co-factor is skipped and the reference's own order continues, so 13824 gets
+    K = 108 (the reference's get_had108 table = Paley-107) x H_128.  Every size the reference accepts gives the same (hadK, K)."""
     for K in (172, 156, 144, 140, 108, 60, 52, 36, 28, 40, 20, 12):
         if n % K == 0:
-            assert is_pow2(n // K), f"cannot build a Hadamard transform of size {n} = {K} x {n // K}"
+            if not is_pow2(n // K):
+                assert not strict, f"cannot build a Hadamard transform of size {n} = {K} x {n // K}"
+                continue
             if K in _PALEY:
                 H = paley_hadamard(_PALEY[K])
             elif K == 40:
@@ -91,6 +97,8 @@ def kernel_rotation_params(n, device):
     m = n // K
     if n == 8960:
         return 140, hadK.float().contiguous().to(device)
+    if n == 13824:
+        return 108, hadK.float().contiguous().to(device)
     if m < 128:
         return None
     kk = K * (m // 128)
