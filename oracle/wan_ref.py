@@ -67,8 +67,41 @@ def static_fake_quant(w, n_bits=8, sym=False):
     return (q + zp) * delta
 
 
+def hadamard_rotation(signs, strict=True):
+    """x -> x.double() @ R for R = random_hadamard_matrix with the sign draw `signs` (Q/quarot/quarot_utils.py:186-192), evaluated
+    WITHOUT the dense matrix: row i of R is s_i * hadU(e_i), so x @ R == hadU(x * s) (qdiff_ref.hadamard_from_signs); hadU is
+    qdiff_ref.matmul_hadU's restatement of quarot_utils.matmul_hadU (:158-179) in float64, on the tensor's device.  For widths where
+    the dense fp64 matrix is impractical (13824 x 13824 = 1.5 GB).  strict=False: the repo-defined K for 13824 (qdiff_ref.had_k)."""
+    from oracle import qdiff_ref as qr
+
+    s64 = torch.as_tensor(signs, dtype=torch.float64)
+
+    def apply(x):
+        n = x.shape[-1]
+        hadK, K = qr.had_k(n, strict)
+        m = n // K
+        v = (x.double() * s64.to(x.device)).reshape(-1, K, m)
+        h = 1
+        while h < m:
+            v = v.reshape(-1, K, m // (2 * h), 2, h)
+            a, b = v[..., 0, :], v[..., 1, :]
+            v = torch.stack([a + b, a - b], dim=-2).reshape(-1, K, m)
+            h *= 2
+        if K > 1:
+            v = torch.matmul(torch.from_numpy(hadK.astype("float64")).to(x.device), v)
+        import numpy as np
+        return v.reshape(x.shape) / float(np.sqrt(np.float32(n)))  # fp32 sqrt, as the reference
+
+    return apply
+
+
+def _rotate(x, rotation):
+    """x.double() @ R for a dense fp64 R, or the same product through hadamard_rotation's callable."""
+    return rotation(x) if callable(rotation) else x.double() @ rotation
+
+
 class FakeQuantLinear:
-    """QuantizedLinear / ViDiTQuantizedLinear forward on a 2-D input."""
+    """QuantizedLinear / ViDiTQuantizedLinear forward on a 2-D input.  `rotation`: the fp64 matrix R, or hadamard_rotation(signs)."""
 
     def __init__(self, weight, bias, w_bits=8, a_bits=8, w_sym=False, channel_mask=None, rotation=None):
         self.bias = None if bias is None else bias.float()
@@ -78,12 +111,12 @@ class FakeQuantLinear:
             self.weight = static_fake_quant(w, w_bits, w_sym)  # quant_layer.py:38-39
         else:  # viditq_quant_layer.py:40-50: quantise, rotate, quantise again
             w1 = static_fake_quant(_div(w, channel_mask.reshape(1, -1)), w_bits, w_sym)
-            self.weight = static_fake_quant((w1.double() @ rotation).float(), w_bits, w_sym)
+            self.weight = static_fake_quant(_rotate(w1, rotation).float(), w_bits, w_sym)
         self.a_bits = a_bits
 
     def __call__(self, x):
         if self.mask is not None:  # viditq_quant_layer.py:62-63
-            x = ((x * self.mask.reshape(1, -1)).double() @ self.R).float()
+            x = _rotate(x * self.mask.reshape(1, -1), self.R).float()
         return _linear(dyn_fake_quant(x, self.a_bits), self.weight, self.bias)
 
 

@@ -256,6 +256,107 @@ def test_kernel_mode_block_with_vidit_and_fp_layers_vs_oracle():
     assert err < 1e-2
 
 
+def test_config5_viditq_block_14b_shapes_rotated_4bit_ffn_vs_oracle_and_quality():
+    """quant_configs/w4a8_mixed_viditq.yaml on one 14B-shape block (dim 5120, ffn 13824, 40 heads): FFN weights 4 bit (packed), the
+    rest 8, ViDiT-Q mask + rotation on self-attention q / k / v AND on ffn.0 (5120 = 40 x 128) / ffn.2 (13824 = 108 x 128: the width
+    the reference's get_hadK asserts on; its own K = 108 branch here, csrc/rotate108.hip).  Masks from the activations the FP block
+    really sees.  (a) parity: kernel-mode block vs the simulation oracle with the same masks / signs / bit-widths; (b) quality: the
+    rotated 4-bit FFN against the plain 4-bit FFN of w4a8_mixed.yaml, both measured against the FP block."""
+    import os
+
+    from qdiff import config as qcfg
+    from qdiff.base.quant_layer import QuantizedLinear
+    from wan import calib, ops
+    from wan.modules.model import WanModel
+    from wan.quant_wanx import QuantWanModel
+    from wan.quant_wanx_hip import _FpSrc
+
+    dim, ffn, heads, grid, lc = 5120, 13824, 40, (1, 6, 8), 32
+    qdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "wan2.1-quantization_amd", "quant_configs")
+    torch.manual_seed(0)
+    with torch.device(DEV):
+        fp = WanModel(dim=dim, ffn_dim=ffn, num_heads=heads, num_layers=1, text_dim=64, freq_dim=64).eval()
+    blk = make_block(dim, ffn, heads, 0)
+    g = torch.Generator().manual_seed(5)
+    # outlier INPUT channels of the FFN weights, as trained DiTs have them: what a 4-bit grid per output row pays for
+    for lin_ in (blk.ffn[0], blk.ffn[2]):
+        cols = torch.randperm(lin_.in_features, generator=g)[: lin_.in_features // 200]
+        lin_.weight.data[:, cols] *= 8.0
+    fp.blocks[0].load_state_dict(blk.state_dict())
+    sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    n_tok = grid[0] * grid[1] * grid[2]
+    x = torch.randn(n_tok, dim, generator=g)
+    x[:, 5] *= 12.0
+    e0 = torch.randn(1, 6, dim, generator=g) * 0.3
+    ctx = torch.randn(lc, dim, generator=g)
+    freqs = wr.rope_freqs(dim // heads)
+    norm_w = {k: sd[k + ".weight"].float() for k in ("self_attn.norm_q", "self_attn.norm_k", "cross_attn.norm_q", "cross_attn.norm_k")}
+    norm3 = (sd["norm3.weight"].float(), sd["norm3.bias"].float())
+
+    # ---- FP oracle block, recording every Linear's per-channel input absmax (what get_calib_data_wanx.py's hooks collect)
+    seen = {}
+
+    class Rec(wr.FpLinear):
+        def __init__(self, name, w, b):
+            super().__init__(w, b)
+            self.name = name
+
+        def __call__(self, xx):
+            seen[self.name] = xx.abs().amax(dim=0)
+            return super().__call__(xx)
+
+    fp_ref = wr.BlockRef({nm: Rec(nm, sd[nm + ".weight"], sd[nm + ".bias"]) for nm in wr.LINEARS}, norm_w, sd["modulation"], heads, 1e-6, norm3)(
+        x, e0, grid, n_tok, ctx, freqs)
+
+    def build(cfg_name):
+        model = QuantWanModel.from_float(fp, qcfg.load(os.path.join(qdir, cfg_name)))
+        model.quant_layer_refactor()
+        gen = torch.Generator().manual_seed(11)
+        for name, mod in model.named_modules():
+            if isinstance(mod, QuantizedLinear) and (mod.uses_mask or mod.uses_rotation):
+                key = name.split("blocks.0.")[1]
+                calib.init_rotation_and_channel_mask_(mod, name, {name: seen[key].clamp_min(1e-3)[None]}, gen)
+        model.bitwidth_refactor()
+        model.set_init_done()
+        model.hardware_forward_refactor()
+        return model
+
+    rope = ops.rope_table(freqs, grid, DEV)
+    run = lambda m: m.hip_blocks[0](x.to(DEV).clone(), e0.to(DEV), rope, n_tok, _FpSrc(ctx.to(DEV), torch.bfloat16)).float().cpu()  # noqa: E731
+    mv = build("w4a8_mixed_viditq.yaml")
+    b0, hb = mv.blocks[0], mv.hip_blocks[0]
+    assert b0.ffn[0].w_quantizer.n_bits == 4 and b0.ffn[2].w_quantizer.n_bits == 4 and b0.self_attn.q.w_quantizer.n_bits == 8
+    assert hb.ffn0.w_bits == 4 and hb.ffn0.weight.dtype == torch.uint8 and hb.ffn0.rot[0] == 40 and hb.ffn2.rot[0] == 108
+    assert hb.self_attn.q.rot[0] == 40 and hb.self_attn.o.rot is None
+    out_v = run(mv)
+
+    # ---- (a) parity against the simulation oracle with the same masks, signs and bit-widths
+    lin = {}
+    for nm in wr.LINEARS:
+        owner = b0.self_attn if nm.startswith("self_attn") else b0.cross_attn if nm.startswith("cross_attn") else None
+        ql = getattr(owner, nm.split(".")[1]) if owner is not None else b0.ffn[int(nm.split(".")[1])]
+        bits = 4 if nm.startswith("ffn") else 8
+        if ql.rotation_signs is not None:
+            lin[nm] = wr.FakeQuantLinear(sd[nm + ".weight"], sd[nm + ".bias"], bits, 8, False, ql.channel_mask.float().cpu(),
+                                         wr.hadamard_rotation(ql.rotation_signs.cpu(), strict=False))
+        else:
+            lin[nm] = wr.FakeQuantLinear(sd[nm + ".weight"], sd[nm + ".bias"], bits, 8, False)
+    ref_v = wr.BlockRef(lin, norm_w, sd["modulation"], heads, 1e-6, norm3)(x, e0, grid, n_tok, ctx, freqs)
+    err = rel_err(out_v, ref_v)
+    # ---- (b) quality against the FP block: plain 4-bit FFN (w4a8_mixed.yaml) vs rotated 4-bit FFN
+    out_p = run(build("w4a8_mixed.yaml"))
+
+    def psnr(a, b):
+        rng = (b.max() - b.min()).item()
+        return 10 * np.log10(rng * rng / (a.double() - b.double()).pow(2).mean().item())
+
+    ep, ev = rel_err(out_p, fp_ref), rel_err(out_v, fp_ref)
+    print(f"config-5 block with ViDiT on q/k/v + ffn.0 / ffn.2: rel err vs its oracle {err:.2e}; against the FP block: plain W4 FFN rel L2 "
+          f"{ep:.2e} / PSNR {psnr(out_p, fp_ref):.1f} dB, rotated W4 FFN rel L2 {ev:.2e} / PSNR {psnr(out_v, fp_ref):.1f} dB")
+    assert err < 1.5e-2
+    assert ev < 0.7 * ep  # the rotation buys back a good part of what the plain 4-bit grid loses to the outlier channels
+
+
 def test_config5_w4a8_mixed_block_14b_shapes_and_checkpoint_roundtrip(tmp_path):
     """BASELINE config 5 on one 14B-shape block (dim 5120, ffn 13824, 40 heads): quant_configs/w4a8_mixed.yaml ->
     quant_layer_refactor + bitwidth_refactor (FFN weights 4 bit, the rest 8; Q/base/quant_model.py:76-105,
