@@ -128,6 +128,14 @@ int wanq_col_absmax(const void* x, int x_dtype, float* colmax, int64_t rows, int
 int wanq_fake_quant_cols(const void* x, int x_dtype, const float* colmax, void* out, int out_dtype, int n_bits,
                          int64_t rows, int cols, void* stream);
 
+/* Fake-quantisation with a PRECOMPUTED delta of x's own shape, elementwise over n values (n % 8 == 0):
+ *   d = max(delta, 1e-6);  plain (bits == NULL): d' = d / (2^b - 1), out = clamp(rne(x / d'), 0, 2^b - 1) * d'
+ *   bits != NULL (int32 per element): d' = d / (2^bits - 1), out = min(rne(x / d'), 2^bits - 1) * d', 0 bits -> 0.
+ * Replaces DynamicQuantizer.forward_with_quant_params (quant_utils/qdiff/base/base_quantizer.py:164-206: the fake-quant step of
+ *   the reference's block-wise attention-map quantisers, symmetric quantisers only).  Bit-identical for fp32 x.  In place allowed. */
+int wanq_fake_quant_with_delta(const void* x, int x_dtype, const float* delta, const int32_t* bits, void* out, int out_dtype,
+                               int n_bits, int64_t n, void* stream);
+
 /* Per-row min / max / absmax of a weight matrix (StaticQuantizer.init_quant_params statistics,
  *   quant_utils/qdiff/base/base_quantizer.py:70-90).  Any of the outputs may be NULL. */
 int wanq_row_minmax(const void* w, int w_dtype, float* row_min, float* row_max, float* row_absmax,

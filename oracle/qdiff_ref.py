@@ -114,6 +114,31 @@ def mixed_dynamic_fake_quant(x, n_bits, sym):
         return ((q + zp[:, None]) * delta[:, None]).astype(F32)
 
 
+# ------------------------------------------------------------------ A16 fake-quant with a precomputed delta
+def fake_quant_with_delta(x, delta, n_bits=8, mixed_precision=None):
+    """DynamicQuantizer.forward_with_quant_params (Q/base/base_quantizer.py:164-206; symmetric quantisers only, :167): the fake-quant
+    step of the reference's block-wise attention-map quantisers with a PRECOMPUTED delta of x's own shape.  delta < 1e-6 -> 1e-6
+    (:181-189).  Plain: d = delta / (2 n + 1), n = 2**(b-1) - 1, y = clamp(rne(x / d), 0, 2 n + 1) * d (:196-199).  mixed_precision
+    (integer bit-widths, x's shape): levels 2**bits - 1, codes clipped from ABOVE only, 0-bit elements masked to zero (:174-178,
+    :191-195, :203-204).  -> (y fp32, the floored delta)."""
+    x = np.asarray(x, dtype=F32)
+    d0 = np.asarray(delta, dtype=F32).copy()
+    d0[d0 < F32(1e-6)] = F32(1e-6)
+    if mixed_precision is not None:
+        bits = np.asarray(mixed_precision).astype(np.int64)
+        nl = (2 ** bits - 1).astype(np.int64)
+        zero = nl == 0
+        nl = np.where(zero, 255, nl)
+        d = (d0 / nl.astype(F32)).astype(F32)
+        xi = np.round((x / d).astype(F32))
+        xq = np.where(xi > nl, nl.astype(F32), xi).astype(F32)
+        return (xq * d * (~zero)).astype(F32), d0
+    n = 2 ** (n_bits - 1) - 1
+    d = (d0 / F32(2 * n + 1)).astype(F32)
+    xq = np.clip(np.round((x / d).astype(F32)), 0, 2 * n + 1).astype(F32)
+    return (xq * d).astype(F32), d0
+
+
 # ------------------------------------------------------------------ A1 static per-channel
 def static_quant_params(w, n_bits=8, sym=False):
     """StaticQuantizer.init_quant_params.  Q/base/base_quantizer.py:70-99.

@@ -680,3 +680,30 @@ def test_rotate_13824_dtypes_outputs_and_viditq_layer():
     y_ref = (xq.astype(np.float64) * xs[:, None]) @ w2.astype(np.float64).T + b.numpy()
     y = vl(x.to(DEV))
     assert np.abs(y.cpu().numpy() - y_ref).max() < 5e-3 * np.abs(y_ref).max() + 1e-3
+
+
+def test_forward_with_quant_params_vs_reference_golden(golden):
+    """DynamicQuantizer.forward_with_quant_params (Q/base/base_quantizer.py:164-206: fake-quant with a precomputed delta of x's shape,
+    optionally a per-element bit-width map) as one HIP launch, against what the reference's own method returned
+    (tests/golden/make_golden_fwqp.py): bit for bit for fp32 inputs -- the plain 8 / 4-bit form on an attention-map-like tensor and on
+    signed scores, the mixed form with bits in {0, 2, 4, 8}, delta floored in place; bf16 input within one bf16 rounding."""
+    from qdiff import config as qcfg
+    from qdiff.base.base_quantizer import DynamicQuantizer
+
+    g = golden("a16_forward_with_quant_params")
+    for b in (8, 4):
+        dq = DynamicQuantizer(qcfg.create({"n_bits": b, "sym": True}))
+        d = t(g["delta"], torch.float32)
+        y = dq.forward_with_quant_params(t(g["x"], torch.float32), d)
+        assert np.array_equal(y.cpu().numpy(), g[f"y{b}"]) and np.array_equal(d.cpu().numpy(), g[f"delta_after{b}"])
+        ys = dq.forward_with_quant_params(t(g["xs"], torch.float32), t(g["delta_s"], torch.float32))
+        assert np.array_equal(ys.cpu().numpy(), g[f"ys{b}"])
+    dq = DynamicQuantizer(qcfg.create({"n_bits": 8, "sym": True}))
+    bits = t(g["bits"], torch.int64)
+    assert np.array_equal(dq.forward_with_quant_params(t(g["x"], torch.float32), t(g["delta"], torch.float32), bits).cpu().numpy(), g["y_mixed"])
+    assert np.array_equal(dq.forward_with_quant_params(t(g["xs"], torch.float32), t(g["delta_s"], torch.float32), bits).cpu().numpy(), g["ys_mixed"])
+    yb = dq.forward_with_quant_params(t(g["x"], torch.bfloat16), t(g["delta"], torch.float32))
+    ref = qr.fake_quant_with_delta(t(g["x"], torch.bfloat16).float().cpu().numpy(), g["delta"], 8)[0]
+    assert yb.dtype == torch.bfloat16 and np.abs(yb.float().cpu().numpy() - ref).max() <= 2 ** -8 * np.abs(ref).max()
+    with pytest.raises(AssertionError):
+        DynamicQuantizer(qcfg.create({"n_bits": 8, "sym": False})).forward_with_quant_params(t(g["x"], torch.float32), t(g["delta"], torch.float32))

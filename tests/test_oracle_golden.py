@@ -330,6 +330,22 @@ def test_a7_mixed_precision_dynamic_quantizer_vs_reference(golden, bits, sym):
         assert np.abs(y - g["y6"]).max() < 2e-5 * np.abs(g["y6"]).max()
 
 
+def test_a16_forward_with_quant_params_vs_reference(golden):
+    """DynamicQuantizer.forward_with_quant_params (base_quantizer.py:164-206) on an attention-map-like tensor and on signed scores,
+    with block-maximum deltas of x's shape: plain 8 / 4 bit and the per-element bit-width map {0, 2, 4, 8}; bit for bit, including the
+    in-place floor of delta and the missing lower clamp of the mixed form."""
+    g = golden("a16_forward_with_quant_params")
+    for b in (8, 4):
+        y, d = qr.fake_quant_with_delta(g["x"], g["delta"], b)
+        assert np.array_equal(y, g[f"y{b}"]) and np.array_equal(d, g[f"delta_after{b}"])
+        assert np.array_equal(qr.fake_quant_with_delta(g["xs"], g["delta_s"], b)[0], g[f"ys{b}"])
+    assert (g["delta"] < 1e-6).any() and (g["delta_after8"] >= np.float32(1e-6)).all()
+    assert np.array_equal(qr.fake_quant_with_delta(g["x"], g["delta"], 8, g["bits"])[0], g["y_mixed"])
+    assert np.array_equal(qr.fake_quant_with_delta(g["xs"], g["delta_s"], 8, g["bits"])[0], g["ys_mixed"])
+    assert (g["ys_mixed"] < 0).any() and not (g["ys8"] < 0).any()   # the mixed form does not clamp from below, the plain one does
+    assert not g["y_mixed"][g["bits"] == 0].any()
+
+
 def test_block_oracle_on_sampled_rows_equals_the_full_block():
     """BlockRef.rows (what the headline-size block test compares against) == BlockRef.__call__ on those rows: every step but the
     self-attention keys / values is row-local.  ViDiT layers on q / k / v as in the headline configuration."""

@@ -697,6 +697,55 @@ extern "C" int wanq_fake_quant_cols(const void* x, int x_dtype, const float* col
   return check_launch("wanq_fake_quant_cols");
 }
 
+// ------------------------------------------------------------------------------ fake-quant with a precomputed delta
+// DynamicQuantizer.forward_with_quant_params (Q/base/base_quantizer.py:164-206): elementwise, delta has x's shape; optional per-element
+// bit-widths (`mixed_precision`).  IEEE divisions, as the reference's torch ops (an HBM-bound pass: 12-16 B per element).
+namespace wanq {
+__global__ __launch_bounds__(256) void fake_quant_delta_kernel(const void* x, int x_dt, const float* delta, const int32_t* bits, void* out,
+                                                               int out_dt, float levels, int64_t chunks) {
+  for (int64_t ch = (int64_t)blockIdx.x * 256 + threadIdx.x; ch < chunks; ch += (int64_t)gridDim.x * 256) {
+    float v[8], d[8];
+    load8_rt(x, x_dt, ch * 8, v);
+    Io<F32>::load8(delta, ch * 8, d);
+    int b[8];
+    if (bits) {
+      const int4 b0 = *reinterpret_cast<const int4*>(bits + ch * 8), b1 = *reinterpret_cast<const int4*>(bits + ch * 8 + 4);
+      b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float dj = d[j] < 1e-6f ? 1e-6f : d[j];  // :181-189
+      if (bits) {  // levels 2^bits - 1; 0 bits: computed as 8 bits, then masked (:174-178, :203-204); clipped from above only (:194)
+        const bool zero = b[j] == 0;
+        const float nl = zero ? 255.f : (float)((1u << b[j]) - 1u);
+        dj = dj / nl;
+        const float xi = rintf(v[j] / dj);
+        v[j] = zero ? 0.f : (xi > nl ? nl : xi) * dj;
+      } else {     // :196-199
+        dj = dj / levels;
+        v[j] = __builtin_amdgcn_fmed3f(rintf(v[j] / dj), 0.f, levels) * dj;
+      }
+    }
+    store8_rt(out, out_dt, ch * 8, v);
+  }
+}
+}  // namespace wanq
+
+extern "C" int wanq_fake_quant_with_delta(const void* x, int x_dtype, const float* delta, const int32_t* bits, void* out, int out_dtype,
+                                          int n_bits, int64_t n, void* stream) {
+  WANQ_REQUIRE(x && delta && out, WANQ_E_ARG, "wanq_fake_quant_with_delta: NULL pointer");
+  WANQ_REQUIRE(is_fp(x_dtype) && is_fp(out_dtype), WANQ_E_ARG, "wanq_fake_quant_with_delta: bad dtype code");
+  WANQ_REQUIRE(n_bits >= 2 && n_bits <= 16, WANQ_E_ARG, "wanq_fake_quant_with_delta: n_bits=%d must be in [2, 16]", n_bits);
+  WANQ_REQUIRE(n >= 0 && n % 8 == 0 && n < (1ll << 40), WANQ_E_SHAPE, "wanq_fake_quant_with_delta: n=%lld must be a multiple of 8", (long long)n);
+  if (n == 0) return WANQ_OK;
+  int64_t blocks = (n / 8 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  // symmetric quantiser: n_levels = 2^(b-1) - 1, the unsigned range of this method is 2 n_levels + 1 = 2^b - 1
+  hipLaunchKernelGGL(fake_quant_delta_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, x_dtype, delta, bits, out, out_dtype,
+                     (float)((1u << n_bits) - 1u), n / 8);
+  return check_launch("wanq_fake_quant_with_delta");
+}
+
 extern "C" int wanq_row_minmax(const void* w, int w_dtype, float* row_min, float* row_max, float* row_absmax,
                                int64_t rows, int cols, void* stream) {
   WANQ_REQUIRE(w && (row_min || row_max || row_absmax), WANQ_E_ARG, "wanq_row_minmax: NULL pointer");

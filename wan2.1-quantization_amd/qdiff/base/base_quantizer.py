@@ -135,6 +135,18 @@ class DynamicQuantizer(BaseQuantizer):
         self.delta, self.zero_point = qs[0].unsqueeze(-1), torch.zeros(rows, 1, device=x.device)
         return q, qs[0], qs[1]
 
+    def forward_with_quant_params(self, x, delta, mixed_precision=None):
+        """base_quantizer.py:164-206: fake-quant with a PRECOMPUTED delta of x's shape (the reference's block-wise attention-map and
+        pre-softmax quantisers), optionally with a per-element bit-width tensor (0 bits = masked to zero).  Symmetric quantisers only,
+        as the reference asserts; like the reference, `delta` is floored at 1e-6 IN PLACE.  One HIP launch (wanq_fake_quant_with_delta)."""
+        assert self.sym
+        if delta.shape != x.shape:
+            delta = delta.expand_as(x)
+        d32 = delta if (delta.dtype == torch.float32 and delta.is_contiguous()) else delta.float().contiguous()
+        d32.clamp_min_(1e-6)
+        bits = None if mixed_precision is None else mixed_precision.to(device=x.device, dtype=torch.int32).expand_as(x).contiguous()
+        return fused.fake_quant_with_delta(x.contiguous(), d32, self.n_bits, bits)
+
     def quantize(self, x):
         assert x.dim() == 2
         if not self.sym:  # (8 bits: codes live in int8 storage, which saturates the 2^b-th level of the reference's loose clamp, D9)

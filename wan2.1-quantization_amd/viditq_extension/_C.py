@@ -57,6 +57,7 @@ PROTOTYPES = {
     "wanq_weight_export_f16": [_vp, _i, _vp, _vp, _vp, _i64, _i, _vp],
     "wanq_rmsnorm_rope": [_vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _i64, _i64, _f, _vp],
     "wanq_fake_quant_cols": [_vp, _i, _vp, _vp, _i, _i, _i64, _i, _vp],
+    "wanq_fake_quant_with_delta": [_vp, _i, _vp, _vp, _vp, _i, _i, _i64, _vp],
     "wanq_rmsnorm_rope_scatter": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _i64, _i64, _f, _vp],
     "wanq_rmsnorm_rope_q8": [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i64, _i, _i, _i64, _i64, _f, _vp],
     "wanq_attention_qk8_fwd": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i, _i64, _i64, _i, _i, _i64, _i64, _i64, _i64, _f, _i, _vp, _i64, _vp],

@@ -208,6 +208,32 @@ def col_absmax_(running_max, x):
     return running_max
 
 
+def fake_quant_with_delta(x, delta, n_bits=8, bits=None):
+    """DynamicQuantizer.forward_with_quant_params as one elementwise launch: x fake-quantised with a precomputed fp32 `delta` of its
+    own shape on the unsigned range 2^b - 1, or with a per-element int32 bit-width map `bits` (0 = masked to zero)."""
+    _C.check_gpu("x", x)
+    _C.check_contig("x", x)
+    _C.check_dtype("x", x, *_FP)
+    _C.check_gpu("delta", delta)
+    _C.check_contig("delta", delta)
+    _C.check_dtype("delta", delta, torch.float32)
+    _C.check_shape("delta", delta, *x.shape)
+    if bits is not None:
+        _C.check_gpu("bits", bits)
+        _C.check_contig("bits", bits)
+        _C.check_dtype("bits", bits, torch.int32)
+        _C.check_shape("bits", bits, *x.shape)
+    _C.check_same_device(x, delta, bits)
+    n = x.numel()
+    if n % 8:
+        raise RuntimeError(f"fake_quant_with_delta: {n} elements, must be a multiple of 8")
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _C.call("wanq_fake_quant_with_delta", _C.ptr(x), _C.dt(x), _C.ptr(delta), _C.ptr(bits), _C.ptr(out), _C.dt(out), int(n_bits), n,
+                _C.stream())
+    return out
+
+
 def fake_quant_cols_(x, n_bits=8, colmax=None):
     """In place: every column of x [rows, cols] fake-quantised with its own dynamic symmetric scale over all rows (the v recipe of
     the reference's quantized attention: per (head, channel) over all tokens).  Returns (x, colmax)."""
