@@ -204,10 +204,18 @@ int wanq_attention_fwd(const void* q, const void* k, const void* v, void* o, int
  * wanq_attention_split_workspace() gives the bytes `workspace` (16-byte aligned, device memory) must hold; splits <= 1 or
  * more splits than 64-key tiles fall back to fewer.  No counterpart in the reference (flash_attn picks its own splits). */
 int64_t wanq_attention_split_workspace(int64_t Lq, int heads, int head_dim, int splits);
+
 int wanq_attention_fwd_split(const void* q, const void* k, const void* v, void* o, int dtype, int64_t Lq,
                              int64_t Lk, int heads, int head_dim, int64_t q_stride, int64_t k_stride,
                              int64_t v_stride, int64_t o_stride, float scale, int splits, void* workspace,
                              int64_t workspace_bytes, void* stream);
+
+/* Diagnostic: which form of the bf16 attention kernel wanq_attention_fwd launches.  The kernel exists with 8 waves per workgroup
+ * (256 queries, three ring stages, one workgroup per CU) and with 4 (128 queries, two stages, two workgroups per CU); key sequences
+ * up to `nw4_keys` run the 4-wave form (start-up default 1024 or WANQ_ATTN_NW4_KEYS: cross-attention), longer ones the 8-wave form.
+ * 0 = always 8 waves, a large value = always 4, -1 = back to the start-up value.  Process-wide; returns the previous setting.
+ * Outputs are bit-identical across the two forms (tests/test_gpu_block.py).  No reference counterpart. */
+int64_t wanq_attention_select_form(int64_t nw4_keys);
 
 /* Quantized Q.K^T (the reference's `attn.qk` fake-quant recipe, quant_attn.py:168-174, run on the integer matrix cores):
  *   o[q,h,:] = softmax_k( (q8[q,h,:] . k8[k,h,:]) * delta_q[h][q] * delta_k[h][k] * scale ) v[k,h,:]

@@ -146,6 +146,11 @@ def test_gemm_kernel_selection_is_a_host_side_setting(lib):
     assert lib.wanq_gemm_select_kernel(1) == 2
     assert lib.wanq_gemm_select_kernel(7) == -1 and lib.wanq_gemm_select_kernel(-1) == -1
     assert lib.wanq_gemm_select_kernel(prev) == 1
+    lib.wanq_attention_select_form.restype = ctypes.c_int64
+    lib.wanq_attention_select_form.argtypes = [ctypes.c_int64]
+    prev = lib.wanq_attention_select_form(0)              # which form of the bf16 attention kernel later calls launch (-1 = start-up value)
+    assert prev == -1 and lib.wanq_attention_select_form(1 << 40) == 0 and lib.wanq_attention_select_form(-5) == 1 << 40
+    assert lib.wanq_attention_select_form(-1) == -1
 
 
 def test_rehearsal_switch_is_refused_unless_exactly_one_gpu_is_visible(monkeypatch, capsys):

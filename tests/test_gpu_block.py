@@ -179,6 +179,37 @@ def test_flash_attention_split_kv_matches_unsplit_and_fp32(Lq, Lk, H, klen, spli
     assert (many.float().cpu() - ref).abs().max().item() < 3e-2 and rel_err(many.float().cpu(), ref) < 1e-2
 
 
+@pytest.mark.parametrize("Lq,Lk,H,klen", [(300, 300, 2, None), (515, 640, 12, 601), (1, 17, 1, None), (17, 65, 1, 33), (100, 512, 2, None),
+                                           (130, 1100, 2, 1061), (257, 1500, 3, None), (2050, 2050, 4, None)])
+def test_flash_attention_both_workgroup_forms_bit_identical(Lq, Lk, H, klen):
+    """The bf16 kernel exists with 8 waves per workgroup (three ring stages, one workgroup per CU: the long self-attention) and with 4
+    (two stages, two workgroups per CU: cross-attention and every key sequence up to 1024 by default).  `wanq_attention_select_form`
+    forces either form, so that BOTH see the edge cases whatever the dispatch rule is: one query, one ragged tile, a masked second tile,
+    ragged key counts on either side of the default bound.  Same arithmetic per wave -> bit-identical outputs; each within the usual
+    tolerance of the fp32 definition."""
+    from viditq_extension import _C
+    from wan import ops
+
+    d = 128
+    g = torch.Generator().manual_seed(Lq * 31 + Lk)  # (the data of test_flash_attention_vs_fp32_softmax for the shapes they share)
+    q = (torch.randn(Lq, H * d, generator=g) * 1.5).to(torch.bfloat16)
+    k = (torch.randn(Lk, H * d, generator=g) * 1.5).to(torch.bfloat16)
+    v = torch.randn(Lk, H * d, generator=g).to(torch.bfloat16)
+    if Lk > 70:
+        k[69] *= 4.0
+    ref = wr.attention(q.float().view(Lq, H, d), k.float().view(Lk, H, d), v.float().view(Lk, H, d), klen).reshape(Lq, H * d)
+    prev = _C.lib.wanq_attention_select_form(0)           # always 8 waves
+    try:
+        o8 = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), H, klen, splits=1)
+        _C.lib.wanq_attention_select_form(1 << 40)        # always 4 waves
+        o4 = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), H, klen, splits=1)
+    finally:
+        _C.lib.wanq_attention_select_form(prev)
+    assert torch.equal(o8, o4)
+    # accuracy of both (they are one result): the rel-Frobenius bar of test_flash_attention_vs_fp32_softmax, which carries the abs bar on its data
+    assert rel_err(o8.float().cpu(), ref) < 1e-2
+
+
 def test_attention_split_heuristic():
     from wan import ops
 

@@ -1193,6 +1193,8 @@ struct Qk8Args {  // int8 Q.K^T operands (NULL q8 = the bf16 form)
   int64_t q8_stride, k8_stride, qs_stride, ks_stride;
 };
 
+static volatile int64_t g_nw4_keys = -1;  // wanq_attention_select_form
+
 template <bool SPLIT, bool QK8>
 static void launch_attn(const AttnParams& p, dim3 grid, hipStream_t st) {
   constexpr int lds = 3 * (QK8 ? AT_STAGE8 : AT_STAGE);
@@ -1277,8 +1279,9 @@ static int attention_impl(const void* q, const void* k, const void* v, void* o, 
       hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(512), 2 * AT_STAGE, st, p);
     } else if (use_m16()) {
       // 4-wave workgroups of 128 queries, two per CU (see attn_fwd16_kernel), up to WANQ_ATTN_NW4_KEYS keys (0 = never)
-      static const int64_t nw4_keys = [] { const char* e = getenv("WANQ_ATTN_NW4_KEYS"); return e ? atoll(e) : (int64_t)WANQ_ATTN_NW4_KEYS_DEFAULT; }();
-      if (Lk <= nw4_keys) {
+      static const int64_t nw4_env = [] { const char* e = getenv("WANQ_ATTN_NW4_KEYS"); return e ? atoll(e) : (int64_t)WANQ_ATTN_NW4_KEYS_DEFAULT; }();
+      const int64_t nw4_sel = g_nw4_keys;  // wanq_attention_select_form: -1 = the start-up value
+      if (Lk <= (nw4_sel >= 0 ? nw4_sel : nw4_env)) {
         const dim3 grid4((unsigned)((Lq + 4 * AT_QW - 1) / (4 * AT_QW)), (unsigned)heads);
         hipLaunchKernelGGL((attn_fwd16_kernel<false, false, 4>), grid4, dim3(256), 2 * AT_STAGE, st, p);
       } else {
@@ -1327,6 +1330,12 @@ static int attention_impl(const void* q, const void* k, const void* v, void* o, 
 extern "C" int64_t wanq_attention_split_workspace(int64_t Lq, int heads, int head_dim, int splits) {
   if (splits <= 1) return 0;
   return (int64_t)splits * Lq * heads * (head_dim + 2) * (int64_t)sizeof(float);
+}
+
+extern "C" int64_t wanq_attention_select_form(int64_t nw4_keys) {
+  const int64_t prev = g_nw4_keys;
+  g_nw4_keys = nw4_keys < -1 ? -1 : nw4_keys;
+  return prev;
 }
 
 extern "C" int wanq_attention_fwd(const void* q, const void* k, const void* v, void* o, int dtype, int64_t Lq,

@@ -69,6 +69,7 @@ PROTOTYPES = {
     "wanq_attention_fwd": [_vp, _vp, _vp, _vp, _i, _i64, _i64, _i, _i, _i64, _i64, _i64, _i64, _f, _vp],
     "wanq_attention_fwd_split": [_vp, _vp, _vp, _vp, _i, _i64, _i64, _i, _i, _i64, _i64, _i64, _i64, _f, _i, _vp, _i64, _vp],
     "wanq_attention_split_workspace": [_i64, _i, _i, _i],
+    "wanq_attention_select_form": [_i64],
     "wanq_attention_map_workspace": [_i64, _i64, _i],
     "wanq_attention_map_quant_fwd": [_vp, _vp, _vp, _vp, _i, _i64, _i64, _i, _i, _i64, _i64, _i64, _i64, _f, _i, _i, _vp, _i64, _vp],
     "wanq_attention_map_quant_qk8_fwd": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i, _i64, _i64, _i, _i, _i64, _i64, _i64, _i64, _f, _i, _i,
@@ -80,6 +81,7 @@ for _name, _args in PROTOTYPES.items():
     _fn.restype = ctypes.c_int
 lib.wanq_last_error.restype = ctypes.c_char_p
 lib.wanq_attention_split_workspace.restype = ctypes.c_int64
+lib.wanq_attention_select_form.restype = ctypes.c_int64
 lib.wanq_attention_map_workspace.restype = ctypes.c_int64
 lib.wanq_abi_version.restype = ctypes.c_int
 if lib.wanq_abi_version() != ABI_VERSION:
