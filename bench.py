@@ -453,7 +453,9 @@ def main():
              "layernorm_rotate_quant_x3": "rotate_kernel<12,1,4,LN,MULTI> (LayerNorm + modulate + ViDiT scale / rotate + quantise for q, k, v)",
              "layernorm_rotate_quant": "rotate_kernel<..., LN> (LayerNorm + modulate + ViDiT scale / rotate + quantise, one consumer)",
              "rotate_quant": "rotate_kernel / rotate140_kernel (ViDiT scale / rotate + quantise)",
-             "rmsnorm_rope": "rmsnorm_rope_kernel (RMSNorm + RoPE on q / k, in place)", "rmsnorm": "rmsnorm_rope_kernel (RMSNorm only: cross-attention q / k)",
+             "rmsnorm_rope": "rmsnorm_rope_kernel (RMSNorm + RoPE on q / k, in place)",
+             "rmsnorm_rope_scatter": "rmsnorm_rope_kernel<..., SC> (RMSNorm + RoPE stored into the Ulysses send images)",
+             "rmsnorm_rope_q8": "rmsnorm_rope_kernel<..., Q8> (RMSNorm + RoPE + per-(token, head) int8 codes for the int8 Q.K^T attention)", "rmsnorm": "rmsnorm_rope_kernel (RMSNorm only: cross-attention q / k)",
              "layernorm": "rowwise_kernel<..., LN> (LayerNorm, fp output)"}
     for tag, ev in htimer.items():
         secs = sum(a.elapsed_time(b) for a, b, _ in ev) * 1e-3

@@ -102,8 +102,39 @@ def test_bench_multi_rank_control_flow_rehearsal(gpus, plan, extra, launcher):
     out = json.loads(lines[0])
     assert out["n_gpus"] == gpus and out["config"]["parallelism"] == plan and out["value"] > 0 and out["config"]["rccl_ranks"] == gpus
     assert out["roofline"]["frac"] > 0 and "REHEARSAL" in out["data"]
+    # round 5: the HBM-bound kernels and the timed calibration pass ride in the same line (rank 0)
+    hb = {r["entry"]: r for r in out["roofline_hbm"]}
+    assert {"layernorm_quant", "quant_sum"} <= set(hb) and ({"rmsnorm_rope", "rmsnorm_rope_scatter"} & set(hb))  # (scatter: under Ulysses)
+    assert all(0 < r["frac"] < 1 and r["bytes_per_launch"] > 0 for r in hb.values())
+    assert out["calibration"]["absmax_launches"] > 0 and out["calibration"]["absmax_TBps"] > 0 and out["calibration"]["ms_per_pass"] > 0
     if extra:  # the flags of BASELINE config 5 (pure Ulysses + sharded packed-W4 / W8 weights), on the 1.3B model
         assert out["config"]["dit_fsdp"]["ranks"] == gpus and "W4A8" in out["config"]["workload"] and "W4A8-mixed" in out["metric"]
+
+
+def test_bench_single_rank_line_has_every_key_of_the_contract():
+    """`python bench.py` at N = 1 on a 9-frame workload (seconds): the driver's contract keys plus `roofline` / `roofline_second_kernel`
+    / `roofline_hbm` / `calibration` / `int8_step` / `quality` / `cpu_baseline` (with `cores_available`)."""
+    import json
+
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, OMP_NUM_THREADS="8")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "WANQ_BENCH_REHEARSE_ON_ONE_GPU"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--frames", "9"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "roofline_second_kernel", "roofline_hbm", "calibration", "int8_step", "quality", "cpu_baseline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 1 and out["unit"] == "steps/s" and out["vs_baseline"] is None and out["data"] == "synthetic"
+    for ro in (out["roofline"], out["roofline_second_kernel"]):
+        assert ro["bound"] == "mfma" and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9 and ro["traffic"] is None  # (not the headline workload)
+    assert all(abs(h["frac"] - h["TBps"] / 8.0) < 1e-9 for h in out["roofline_hbm"])
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and 1 <= cb["cores"] <= cb["cores_available"] and cb["value"] > 0 and cb["cfg_a"]["value"] > 0
 
 
 def test_rccl_backend_single_rank_collective_forms():

@@ -57,7 +57,8 @@ def rmsnorm_rope_scatter(x, weight, rope, head_dim, out, head_map, rows_per_batc
         positions = rope.shape[0]
     with torch.cuda.device(x.device):
         _C.call("wanq_rmsnorm_rope_scatter", _C.ptr(x), _C.dt(x), _C.ptr(weight), _C.ptr(rope), _C.ptr(out), _C.dt(out),
-                _C.ptr(head_map), rows, cols, head_dim, rows_per_batch or rows, positions, float(eps), _C.stream())
+                _C.ptr(head_map), rows, cols, head_dim, rows_per_batch or rows, positions, float(eps), _C.stream(),
+                hbm=("rmsnorm_rope_scatter", 2 * rows * cols * x.element_size() + (min(rows, positions) * head_dim * 4 if rope is not None else 0)))
     return out
 
 
@@ -107,7 +108,8 @@ def rmsnorm_rope_q8(x, weight, rope, head_dim, for_keys, eps=1e-6, want_fp=False
     with torch.cuda.device(x.device):
         _C.call("wanq_rmsnorm_rope_q8", _C.ptr(x), _C.dt(x), _C.ptr(weight), _C.ptr(rope), _C.ptr(out),
                 _C.BF16, _C.ptr(q8.codes), _C.ptr(q8.scales), q8.stride, rows, cols, head_dim, rows, positions, float(eps),
-                _C.stream())
+                _C.stream(), hbm=("rmsnorm_rope_q8", rows * cols * (x.element_size() + 1 + (2 if want_fp else 0)) +
+                                  8 * rows * (cols // head_dim) + (min(rows, positions) * head_dim * 4 if rope is not None else 0)))
     return (q8, out) if want_fp else q8
 
 
