@@ -47,6 +47,17 @@ def dyn_fake_quant(x, n_bits=8):
     return torch.clamp(torch.round(_div(x, delta)), -n - 1, n) * delta
 
 
+def dyn_fake_quant_asym(x, n_bits=8, eps=1e-8):
+    """DynamicQuantizer.forward, asymmetric branch (Q/base/base_quantizer.py:130-149,154-161).  x: [T, C] fp32."""
+    n = 2 ** n_bits
+    hi = x.amax(dim=1, keepdim=True).clamp_min(0.0)
+    lo = x.amin(dim=1, keepdim=True).clamp_max(0.0)
+    delta = _div(hi - lo, float(n - 1))
+    delta = torch.where(delta < eps, torch.full_like(delta, eps), delta)
+    zp = torch.round(_div(lo, delta)) + n / 2
+    return (torch.clamp(torch.round(_div(x, delta)) - zp, -n - 1, n) + zp) * delta
+
+
 def static_params(w, n_bits=8, sym=False):
     """StaticQuantizer.init_quant_params (Q/base/base_quantizer.py:70-99)."""
     if sym:
@@ -103,7 +114,8 @@ def _rotate(x, rotation):
 class FakeQuantLinear:
     """QuantizedLinear / ViDiTQuantizedLinear forward on a 2-D input.  `rotation`: the fp64 matrix R, or hadamard_rotation(signs)."""
 
-    def __init__(self, weight, bias, w_bits=8, a_bits=8, w_sym=False, channel_mask=None, rotation=None):
+    def __init__(self, weight, bias, w_bits=8, a_bits=8, w_sym=False, channel_mask=None, rotation=None, a_sym=True):
+        self.a_sym = a_sym
         self.bias = None if bias is None else bias.float()
         self.mask, self.R = channel_mask, rotation
         w = weight.float()
@@ -117,7 +129,7 @@ class FakeQuantLinear:
     def __call__(self, x):
         if self.mask is not None:  # viditq_quant_layer.py:62-63
             x = _rotate(x * self.mask.reshape(1, -1), self.R).float()
-        return _linear(dyn_fake_quant(x, self.a_bits), self.weight, self.bias)
+        return _linear(dyn_fake_quant(x, self.a_bits) if self.a_sym else dyn_fake_quant_asym(x, self.a_bits), self.weight, self.bias)
 
 
 class FpLinear:
@@ -299,7 +311,7 @@ LINEARS = ("self_attn.q", "self_attn.k", "self_attn.v", "self_attn.o", "cross_at
 
 
 def block_from_state(sd, num_heads, eps=1e-6, quant=True, w_bits=8, a_bits=8, vidit=None, qk_bits=None, cross_qk_bits=None,
-                     v_bits=None, cross_v_bits=None, attn_map=None, cross_attn_map=None):
+                     v_bits=None, cross_v_bits=None, attn_map=None, cross_attn_map=None, a_sym=True):
     """Build a BlockRef from a WanAttentionBlock state dict (CPU tensors).
     vidit: optional {linear name: (channel_mask fp32 [K], rotation fp64 [K,K])}."""
     lin = {}
@@ -307,7 +319,7 @@ def block_from_state(sd, num_heads, eps=1e-6, quant=True, w_bits=8, a_bits=8, vi
         w, b = sd[name + ".weight"], sd.get(name + ".bias")
         if quant:
             cm, R = (vidit or {}).get(name, (None, None))
-            lin[name] = FakeQuantLinear(w, b, w_bits, a_bits, False, cm, R)
+            lin[name] = FakeQuantLinear(w, b, w_bits, a_bits, False, cm, R, a_sym)
         else:
             lin[name] = FpLinear(w, b)
     norm_w = {k: sd[k + ".weight"].float() for k in ("self_attn.norm_q", "self_attn.norm_k", "cross_attn.norm_q", "cross_attn.norm_k")}

@@ -287,6 +287,54 @@ def test_kernel_mode_block_with_vidit_and_fp_layers_vs_oracle():
     assert err < 1e-2
 
 
+@pytest.mark.parametrize("act", [{"n_bits": 8, "sym": False}, {"n_bits": 6, "sym": True}, {"n_bits": 4, "sym": False}])
+def test_kernel_mode_block_with_asymmetric_or_narrow_activations_vs_simulation_oracle(act):
+    """Kernel mode with an activation quantiser the fused producers do not implement -- asymmetric (Q/base/base_quantizer.py:130-149),
+    below 8 bits -- on ALL ten Linears of a block, ViDiT mask + rotation on q / k / v (viditq_quant_layer.py:60-73 feeds whatever
+    `a_quantizer` the config names): every such layer takes the unfused path (fp32 activation -> the layer's own quantiser kernels
+    -> int8 GEMM -> zero-point rank-one term), against the simulation oracle with the same quantiser.  No Wan configuration selects
+    these; the reference's kernel mode has no such path (its kernels are symmetric 8-bit), so the parity target is simulation mode."""
+    from oracle import qdiff_ref as qr
+    from qdiff import config as qcfg
+    from qdiff.base.quant_model import quant_layer_refactor_
+    from qdiff.utils import apply_func_to_submodules
+    from wan import calib, ops
+    from wan.quant_wanx_hip import WanAttentionBlockWithHipKernel, _FpSrc
+
+    dim, ffn, heads, grid, lc = 256, 512, 2, (2, 5, 7), 24
+    blk = make_block(dim, ffn, heads, 7)
+    sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    n_tok = grid[0] * grid[1] * grid[2]
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(n_tok, dim, generator=g)
+    x[:, 3] *= 10.0
+    e0 = torch.randn(1, 6, dim, generator=g) * 0.3
+    ctx = torch.randn(lc, dim, generator=g)
+    freqs = wr.rope_freqs(dim // heads)
+    act_mask = torch.rand(dim, generator=g) * 3 + 0.2
+    cfg = qcfg.create({"weight": {"n_bits": 8, "sym": False}, "act": act, "viditq": {"alpha": 0.5665, "layer_name_regex": r"self_attn\.(q|k|v)$"}})
+    blk = blk.to(DEV)
+    apply_func_to_submodules(blk, torch.nn.Linear, quant_layer_refactor_, name=None, parent_module=None, quant_config=cfg, full_name=None,
+                             remain_fp_regex=None)
+    gen = torch.Generator().manual_seed(11)
+    vidit = {}
+    for name in ("q", "k", "v"):
+        lin = getattr(blk.self_attn, name)
+        assert type(lin).__name__ == "ViDiTQuantizedLinear", type(lin).__name__
+        calib.init_rotation_and_channel_mask_(lin, "x", {"x": act_mask[None]}, gen)
+        vidit["self_attn." + name] = (lin.channel_mask.cpu(), torch.from_numpy(qr.hadamard_from_signs(lin.rotation_signs.numpy())))
+    ref = wr.block_from_state(sd, heads, quant=True, a_bits=act["n_bits"], a_sym=act["sym"], vidit=vidit)(x, e0, grid, n_tok, ctx, freqs)
+    ref8 = wr.block_from_state(sd, heads, quant=True, vidit=vidit)(x, e0, grid, n_tok, ctx, freqs)
+    fp = wr.block_from_state(sd, heads, quant=False)(x, e0, grid, n_tok, ctx, freqs)
+    hb = WanAttentionBlockWithHipKernel.from_float(blk, None)
+    assert all(l.act_quantizer is not None for l in (hb.self_attn.q, hb.self_attn.o, hb.cross_attn.k, hb.ffn0, hb.ffn2))
+    out = hb(x.to(DEV).clone(), e0.to(DEV), ops.rope_table(freqs, grid, DEV), n_tok, _FpSrc(ctx.to(DEV), torch.bfloat16)).float().cpu()
+    err, noise = rel_err(out, ref), rel_err(ref, fp)
+    print(f"kernel-mode block, activations {act}: rel err vs its simulation oracle {err:.2e} (the recipe's own distance from FP {noise:.2e}; "
+          f"8-bit symmetric recipe vs this one {rel_err(ref8, ref):.2e})")
+    assert err < 0.5 * noise + 5e-3
+
+
 def test_config5_viditq_block_14b_shapes_rotated_4bit_ffn_vs_oracle_and_quality():
     """quant_configs/w4a8_mixed_viditq.yaml on one 14B-shape block (dim 5120, ffn 13824, 40 heads): FFN weights 4 bit (packed), the
     rest 8, ViDiT-Q mask + rotation on self-attention q / k / v AND on ffn.0 (5120 = 40 x 128) / ffn.2 (13824 = 108 x 128: the width

@@ -28,8 +28,13 @@ class HipLinearW8A8(nn.Module):
     (include/wanq_hip.h); they stay packed in HBM and are expanded in registers inside the GEMM (wanq_gemm_w4a8), the +8 being
     folded into the zero point the epilogue uses (`zp_gemm` = zero_point - 8).
     Optional ViDiT activation transform: `act_premul` fp32 [K] (= channel_mask * rotation signs) and `rot`
-    (had_k, hadk) -- the producer kernel applies hadU(x * premul) before quantising this layer's input."""
+    (had_k, hadk) -- the producer kernel applies hadU(x * premul) before quantising this layer's input.
+    `act_quantizer`: None for the activation quantiser the fused producers implement (8-bit symmetric per token, eps 1e-6: every Wan
+    configuration and the reference's kernels, fused.cu:330-370); otherwise the layer's own qdiff quantiser object (asymmetric,
+    below 8 bits, or the mixed-precision class), and the block takes the UNFUSED path for this layer: fp32 activation -> that
+    quantiser's HIP kernels -> int8 GEMM -> the zero point's rank-one term (WanAttentionBlockWithHipKernel._linear_any_act)."""
     quantized = True
+    act_quantizer = None
 
     def __init__(self, in_features, out_features, bias=True, sym=False, w_bits=8):
         super().__init__()
@@ -65,8 +70,20 @@ class HipLinearW8A8(nn.Module):
         if self.zp_weight is not None:
             self.zp_weight.copy_(zero_point)
 
+    def w_rowsum(self):
+        """sum_k w_dq[n, k] = (sum_k code + K * zero_point) * delta, fp32 [N]: the channel factor of an asymmetric activation
+        quantiser's rank-one term (x_dq = (q + zp_a) * s_a).  From the integer codes the layer holds; cached until they change."""
+        r = self.__dict__.get("_w_rowsum")
+        if r is None:
+            codes = qgemm.unpack_w4(self.weight, bias=8) if self.w_bits == 4 else self.weight
+            zp = self.zp_weight if self.zp_weight is not None else torch.zeros_like(self.scale_weight)
+            r = (codes.sum(dim=1, dtype=torch.float32) + self.in_features * zp) * self.scale_weight
+            self.__dict__["_w_rowsum"] = r
+        return r
+
     def refresh_zp_gemm(self):
         """After scale_weight / zp_weight were loaded from a checkpoint."""
+        self.__dict__.pop("_w_rowsum", None)
         if self.w_bits == 4:
             self.zp_gemm.copy_((self.zp_weight if self.zp_weight is not None else torch.zeros_like(self.scale_weight)) - 8.0)
 
@@ -93,6 +110,9 @@ class HipLinearW8A8(nn.Module):
             m.bias.copy_(ql.bias.detach().float())
         premul, rot = ql._act_transform()
         m.act_premul, m.rot = premul, rot
+        aq = ql.a_quantizer
+        if not aq.sym or aq.n_bits != 8 or aq._sym_floor != 1e-6:
+            m.__dict__["act_quantizer"] = aq  # (not a submodule: the quantiser belongs to the qdiff layer)
         return m
 
     @property
@@ -126,12 +146,6 @@ def _to_hip_linear(lin, n_bits, sym, act_dtype):
 
     if isinstance(lin, QuantizedLinear):
         if lin.quant_mode and lin.w_quantizer is not None and lin.a_quantizer is not None:
-            if not lin.a_quantizer.sym:
-                raise NotImplementedError("kernel mode: the fused producers quantise activations symmetrically per token (every Wan "
-                                          "configuration); asymmetric activations run in simulation mode (qdiff.QuantizedLinear)")
-            if lin.a_quantizer.n_bits != 8:
-                raise NotImplementedError(f"kernel mode: the fused producers emit 8-bit activation codes (W8A8 / W4A8, as the reference's "
-                                          f"kernels: fused.cu:330-370); {lin.a_quantizer.n_bits}-bit activations run in simulation mode")
             return HipLinearW8A8.from_quantized(lin)
         lin = lin.fp_module
     if n_bits is None:
@@ -174,7 +188,8 @@ class _LnSrc:
         whenever the consumers do not all rotate with the same Hadamard parameters."""
         todo = []
         for lin in lins:
-            if not getattr(lin, "quantized", False) or lin.act_key is None or lin.act_key in self.cache or lin.rot is None:
+            if not getattr(lin, "quantized", False) or lin.act_key is None or lin.act_key in self.cache or lin.rot is None or \
+                    lin.act_quantizer is not None:
                 continue
             if lin.act_key not in [l.act_key for l in todo]:
                 todo.append(lin)
@@ -195,6 +210,14 @@ class _LnSrc:
             fused.layernorm_nobias_t2i_fuse(out, self.x, self.gamma, self.shift, self.scale, self.blk.eps)
             self.cache["fp"] = out
         return self.cache["fp"]
+
+    def fp32(self):
+        """The normalised, modulated row in fp32 (what a simulation-mode quantiser sees: model.py:327)."""
+        if "fp32" not in self.cache:
+            out = torch.empty(self.x.shape, dtype=torch.float32, device=self.x.device)
+            fused.layernorm_nobias_t2i_fuse(out, self.x, self.gamma, self.shift, self.scale, self.blk.eps)
+            self.cache["fp32"] = out
+        return self.cache["fp32"]
 
 
 class _FpSrc:
@@ -219,6 +242,12 @@ class _FpSrc:
                 q = fused.rotate_quant(self.t, lin.act_premul, lin.rot, qs[1], qs[0])
             self.cache[key] = (q, qs[0], qs[1])
         return self.cache[key]
+
+    def fp32(self):
+        if "fp32" not in self.cache:
+            t = self.t.float()
+            self.cache["fp32"] = torch.nn.functional.gelu(t, approximate="tanh") if self.gelu else t
+        return self.cache["fp32"]
 
     def fp(self):
         assert not self.gelu, "a pre-activation source has no floating-point view"
@@ -318,6 +347,8 @@ class WanAttentionBlockWithHipKernel(nn.Module):
         """y = lin(src) with the producer / epilogue fusion the layer's kind allows.  With `residual` (the fp32
         stream) the result is residual + y*gate written in place."""
         out_dtype = out_dtype or self.act_dtype
+        if lin.quantized and lin.act_quantizer is not None:
+            return self._linear_any_act(lin, src, out_dtype, gelu, gate, residual)
         if lin.quantized:
             q, s, ssum = src.int8(lin)
             if residual is not None:
@@ -330,6 +361,24 @@ class WanAttentionBlockWithHipKernel(nn.Module):
             fused.gate_residual_into_(residual, y, gate.view(1, -1))
             return residual
         return y
+
+    def _linear_any_act(self, lin, src, out_dtype, gelu, gate, residual):
+        """A quantised Linear whose activation quantiser is not the fused producers' (asymmetric, below 8 bits, the mixed-precision
+        class: Q/base/base_quantizer.py:130-149, mixed_precision_quantizer.py:126-186 -- no Wan configuration, and the reference's
+        kernel mode has no such path at all): the layer's own qdiff quantiser on the fp32 activation (its HIP kernels: row statistics
+        + quantise, the ViDiT transform written out in fp32 first), the int8 GEMM with its plain fp32 epilogue, the asymmetric zero
+        point's rank-one term (zp_a s_a)[token] x rowsum(w_dq)[channel], then GELU / gate + residual unfused."""
+        aq = lin.act_quantizer
+        q, s, ssum = aq.quantize_int8(src.fp32(), lin.act_premul, lin.rot)
+        y = lin(q, s, ssum, torch.float32)
+        if not aq.sym:
+            y = torch.addcmul(y, (aq.zero_point.reshape(-1).float() * s).unsqueeze(1), lin.w_rowsum().unsqueeze(0))
+        if gelu:
+            y = torch.nn.functional.gelu(y, approximate="tanh")
+        if residual is not None:
+            fused.gate_residual_into_(residual, y, gate.view(1, -1))
+            return residual
+        return y.to(out_dtype)
 
     @staticmethod
     def _vq(v, n_bits, k_len):
