@@ -50,6 +50,18 @@ def test_two_ranks_attention_map_quantiser_under_ulysses():
     assert r.stdout.count("sp_rel=0.000e+00") == 2, r.stdout[-2000:]
 
 
+
+def test_two_ranks_cross_attention_map_quantiser_under_ulysses():
+    """cross_attn.attn_map under Ulysses (sp 2): the cross-attention's queries are a token shard, but a key column's step is a maximum
+    over ALL queries -- the block gathers the queries of both ranks for it (rank order == sequence order) and keeps its own rows:
+    bit-equal to the single-rank output (round 4 refused this combination)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(HERE, "sp_rehearsal_worker.py")]
+    env = dict(os.environ, OMP_NUM_THREADS="4", WANQ_REHEARSE_CONFIG="w8a8_all_linears_attn_map_cross.yaml", WANQ_REHEARSE_NO_CFG_PARALLEL="1")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, f"cross attention-map rehearsal failed:\n{r.stdout[-4000:]}\n{r.stderr[-4000:]}"
+    assert r.stdout.count("sp_rel=0.000e+00") == 2, r.stdout[-2000:]
+
 def test_two_ranks_int8_qk_under_ulysses():
     """attn.qk under Ulysses (sp 2): q / k are quantised per (token, head) where RMSNorm + RoPE produces them and the head
     exchange moves int8 codes + fp32 scale planes (no silent bf16 path: r2 ADVICE / VERDICT) -- bit-equal to the single-rank

@@ -523,25 +523,27 @@ class WanAttentionBlockWithHipKernel(nn.Module):
         h = _LnSrc(self, x, self.norm3_weight, self.norm3_bias.view(1, -1), None)
         q = self._linear(ca.q, h)
         k, v = self._context_kv(ctx)
+        # cross_attn.attn_map under sequence parallelism: a rank's queries are a token shard here (the cross-attention is not
+        # exchanged), but a key column's quantisation step is a maximum over ALL queries.  The queries of all ranks are gathered
+        # (rank order == sequence order), every rank evaluates the whole map's statistics on the 512 keys and keeps its own rows:
+        # the numerics of N = 1 bit for bit, for one all-gather of q per block -- an optional recipe, not the headline path.
+        gather_q = self.cross_attn_map is not None and sp is not None and sp.size > 1
+        if gather_q:
+            q = sp.all_gather_rows(q)
         if self.cross_attn_qk8:
             q8 = ops.rmsnorm_rope_q8(q, ca.norm_q_weight, None, d, False, eps=self.eps)
             if self.cross_attn_map is not None:
-                if sp is not None and sp.size > 1:
-                    raise NotImplementedError("cross_attn.attn_map under sequence parallelism (column statistics span the ranks' token shards)")
                 o = ops.attention_map_quant(q8, k, v, H, self.cross_attn_map[0], self.cross_attn_map[1], q_len=seq_len)
             else:
                 o = ops.attention_qk8(q8, k, v, H)
         else:
             ops.rmsnorm_rope_(q, ca.norm_q_weight, None, d, eps=self.eps)
             if self.cross_attn_map is not None:
-                if sp is not None and sp.size > 1:
-                    # a rank's queries are a token shard here (the cross-attention is not exchanged), so a key column's maximum
-                    # over ALL queries would need a MAX all-reduce between the passes: not built -- refuse rather than quantise
-                    # per shard and give N > 1 other numerics than N = 1
-                    raise NotImplementedError("cross_attn.attn_map under sequence parallelism (column statistics span the ranks' token shards)")
                 o = ops.attention_map_quant(q, k, v, H, self.cross_attn_map[0], self.cross_attn_map[1], q_len=seq_len)
             else:
                 o = ops.attention(q, k, v, H)
+        if gather_q:
+            o = sp.shard_rows(o).contiguous()
         self._linear(ca.o, _FpSrc(o), gate=self.ones_gate, residual=x)
 
         # ---- FFN: LN*(1+e4)+e3 -> GEMM -> GELU + quantise -> GEMM (+gate, +residual).  The GELU runs in ffn.2's quantiser when
