@@ -56,6 +56,33 @@ def test_four_entry_points_chain(tmp_path, config):
         assert dpm.shape == fp.shape and torch.isfinite(dpm).all() and not torch.equal(dpm, hw)
 
 
+@pytest.mark.parametrize("config", ["w4a8_mixed.yaml", "w4a8_mixed_viditq.yaml"])
+def test_four_entry_points_chain_mixed_precision(tmp_path, config):
+    """BASELINE config 5's recipe through the entry scripts on the truncated backbone: FFN weights 4 bit (packed in `int_weight.pt`
+    and in HBM), the rest 8, `bitwidth_refactor` driven by the config's regex lists (ptq_wanx.py / quant_generate.py); the second
+    config adds the ViDiT mask + rotation on q / k / v AND on the 4-bit ffn.0 / ffn.2 (8960-wide rotation at these dims)."""
+    qc = os.path.join(PKG, "quant_configs", config)
+    calib = str(tmp_path / "calib.pth")
+    run("fp_generate.py", cwd=tmp_path)
+    fp = torch.load(tmp_path / "fp_latent_0.pt", weights_only=True)
+    run("get_calib_data_wanx.py", "--quant_config", qc, "--calib_data", calib, cwd=tmp_path)
+    run("ptq_wanx.py", "--quant_config", qc, "--calib_data", calib, cwd=tmp_path)
+    iw = torch.load(tmp_path / "checkpoint" / "int_weight.pt", weights_only=True)
+    assert iw["blocks.0.ffn.0.weight"].dtype == torch.uint8 and tuple(iw["blocks.0.ffn.0.weight"].shape) == (8960, 1536 // 2)  # packed nibbles
+    assert iw["blocks.1.ffn.2.weight"].dtype == torch.uint8 and iw["blocks.0.self_attn.q.weight"].dtype == torch.int8
+    qp = torch.load(tmp_path / "checkpoint" / "quant_params.pth", weights_only=True)
+    rotated = [k for k, e in qp.items() if k.endswith("w_quantizer") and e.get("channel_mask") is not None]
+    assert len(rotated) == (10 if "viditq" in config else 0)  # q, k, v, ffn.0, ffn.2 of two blocks
+    run("quant_generate.py", "--quant_config", qc, cwd=tmp_path)
+    hw = torch.load(tmp_path / "quant_latent_0.pt", weights_only=True)
+    run("quant_generate.py", "--quant_config", qc, "--hardware", "false", "--save_file", str(tmp_path / "sim.pt"), cwd=tmp_path)
+    sim = torch.load(tmp_path / "sim.pt", weights_only=True)
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()  # noqa: E731
+    print(f"{config}: kernel-mode vs fp {rel(hw, fp):.3e}; simulation-mode vs fp {rel(sim, fp):.3e}; kernel vs simulation {rel(hw, sim):.3e}")
+    assert hw.shape == fp.shape and torch.isfinite(hw).all()
+    assert rel(hw, fp) < 0.2 and rel(sim, fp) < 0.2 and rel(hw, sim) < 0.08  # 4-bit FFN weights: the recipe itself is ~1e-1 from FP
+
+
 def test_four_entry_points_at_headline_size(tmp_path):
     """The same chain at BASELINE config 2's size -- all 30 blocks, 832x480x81f (L = 32760), W8A8 on all 300 Linears with the
     ViDiT transform on q / k / v -- for 3 UniPC steps: the quantized kernel-mode latent after the whole loop stays within 5e-2

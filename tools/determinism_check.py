@@ -139,3 +139,33 @@ def lc():
 
 
 check("lincomb 3 x 6 latent-sized", lc)
+
+# ---- round 5: the 13824-column transform, the narrow-range quantiser, the fake-quant with a precomputed delta, both attention forms
+from viditq_extension import _C  # noqa: E402
+
+for rows in (67, 1200):
+    x = (torch.randn(rows, 13824, device=DEV, generator=g) * 2).to(torch.bfloat16)
+    pm = torch.randn(13824, device=DEV, generator=g)
+    rot = qu.kernel_rotation_params(13824, DEV)
+
+    def r108():
+        s, u = torch.zeros(rows, device=DEV), torch.zeros(rows, device=DEV)
+        return [fused.rotate_quant(x, pm, rot, u, s), s, u]
+    check(f"rotate108 + quantise [{rows}, 13824]", r108)
+for (rows, C, lv) in [(270, 1536, 31), (33, 8960, 7)]:
+    x = torch.randn(rows, C, device=DEV, generator=g)
+
+    def qlv():
+        s, u = torch.zeros(rows, device=DEV), torch.zeros(rows, device=DEV)
+        return [fused.quant_sum_levels(x, u, s, lv, 0.0), s, u]
+    check(f"quant_rows_levels [{rows}, {C}] levels={lv}", qlv)
+x = torch.rand(512, 512, device=DEV, generator=g)
+d = x.reshape(64, 8, 64, 8).amax(dim=(1, 3), keepdim=True).expand(64, 8, 64, 8).reshape(512, 512).contiguous()
+check("fake_quant_with_delta [512, 512]", lambda: fused.fake_quant_with_delta(x, d, 8))
+q = torch.randn(515, 4 * 128, device=DEV, generator=g).to(torch.bfloat16)
+k = torch.randn(640, 4 * 128, device=DEV, generator=g).to(torch.bfloat16)
+v = torch.randn(640, 4 * 128, device=DEV, generator=g).to(torch.bfloat16)
+for form, name in ((0, "8 waves"), (1 << 40, "4 waves")):
+    prev = _C.lib.wanq_attention_select_form(form)
+    check(f"attention 515 x 640 x 4, {name}", lambda: ops.attention(q, k, v, 4, 601, splits=1))
+    _C.lib.wanq_attention_select_form(prev)
