@@ -188,6 +188,10 @@ def main():
     ap.add_argument("--graph", type=int, default=int(os.environ.get("WANQ_BENCH_GRAPH", "0")), choices=[0, 1],
                     help="1 (single GPU only): the two DiT passes of a step are replayed from a captured HIP graph "
                          "(wan/graph.py); 0 (default): every kernel is launched eagerly -- measured the same (DESIGN.md 5): the host runs ahead")
+    ap.add_argument("--pass-streams", dest="pass_streams", type=int, default=int(os.environ.get("WANQ_PASS_STREAMS", "2")), choices=[1, 2],
+                    help="2 (default; one rank without cfg parallelism): the conditional and the unconditional pass of a step are issued on two "
+                         "HIP streams (wan/utils/two_pass.py, what WanT2V.generate does), so that one pass's kernels fill the other's launch "
+                         "boundaries: 1.033x, bit-equal results; 1: back to back on one stream, as the reference runs them")
     ap.add_argument("--no-context-cache", dest="no_context_cache", action="store_true",
                     help="recompute cross_attn.k / cross_attn.v (+ RMSNorm) of the text context in every DiT pass, as round 2 did: they "
                          "do not depend on the timestep, and by default they are computed once per context tensor and kept "
@@ -325,14 +329,20 @@ def main():
     fused = FusedStep(sched, args.guide, latent0)  # CFG combine + UniPC update: one kernel per step
     graphed = None
     use_graph = [bool(args.graph) and world == 1]
+    two_was_on = args.pass_streams == 2 and world == 1 and not use_graph[0]
     if use_graph[0]:
         from wan.graph import GraphedPasses
         graphed = GraphedPasses(model, latent0, [ctx_c, ctx_u], seq_len)
+
+    from wan.utils.two_pass import TwoPassStreams
+    two = TwoPassStreams(dev, enabled=args.pass_streams == 2 and plan.cfg_degree == 1 and world == 1)
 
     def step(latent, i):
         t = sched.timesteps[i:i + 1]
         if graphed is not None and use_graph[0]:
             cond, uncond = graphed(latent, t)
+        elif two.enabled:
+            cond, uncond = two(lambda c: model([latent], t, [c], seq_len, plan.sp)[0], latent, [ctx_c, ctx_u])
         elif plan.cfg_degree == 2:  # my half of the GPUs runs ONE of the two passes; a 2 MB all-gather joins them
             mine = model([latent], t, [ctx_c if plan.cfg_index == 0 else ctx_u], seq_len, plan.sp)[0]
             cond, uncond = plan.gather_cfg(mine)
@@ -342,6 +352,8 @@ def main():
         return fused.step(cond, uncond, latent, sched.timesteps[i])
 
     latent = latent0
+    if two.enabled and args.warmup == 0:  # the helper's first call runs on one stream (it fills the caches both passes read): keep it untimed
+        two(lambda c: model([latent0], sched.timesteps[0:1], [c], seq_len, plan.sp)[0], latent0, [ctx_c, ctx_u])
     for i in range(args.warmup):
         latent = step(latent, i)
     from wan import ops as wan_ops
@@ -367,6 +379,7 @@ def main():
     # attention launch on the launch stream (about 1400 pairs per step, which is why they stay out of the headline region
     # above; `instrumented_ms_per_step` shows what they cost).  share_of_step = kernel time / wall time of THIS region.
     use_graph[0] = False  # launches must be eager to be bracketed by events
+    two.enabled = False   # ... and on ONE stream: beside another pass's kernels an event pair times the sharing, not the kernel
     timer = GemmTimer()
     atimer = GemmTimer()
     qgemm.set_timer(timer)
@@ -399,7 +412,8 @@ def main():
                                                              "of_MB": round(len(sharded.blocks) * sharded.full_bytes / 1e6, 1),
                                                              "w4_unpack_scratch_MB": round(qgemm.w4_scratch_bytes(dev) / 1e6, 1)},
                    "launch": "hip graph replay of the two DiT passes + 1 fused CFG/scheduler kernel" if graphed is not None else
-                             "eager launches + 1 fused CFG/scheduler kernel",
+                             ("eager launches, the two passes of a step on two HIP streams (wan/utils/two_pass.py)" if two_was_on else "eager launches")
+                             + " + 1 fused CFG/scheduler kernel",
                    "rccl_ranks": dist.get_world_size() if world > 1 else 1,
                    # Ulysses exchange of THIS rank inside the timed region (wan/distributed/parallel.py counts what it hands to
                    # all_to_all_single): bytes leaving the GPU over xGMI per step, and the number of all-to-alls

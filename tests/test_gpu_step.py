@@ -168,3 +168,67 @@ def test_graph_replay_survives_cache_eviction_and_sees_context_updates():
     torch.cuda.synchronize()
     assert torch.equal(outs[0], model([lat], t, [new_ctx], seq_len)[0])
     assert torch.equal(outs[1], want[1])
+
+
+@pytest.mark.parametrize("dims", [(512, 1024, 4, 2, (16, 3, 20, 18)), (1536, 8960, 12, 2, (16, 5, 60, 104))])
+def test_two_pass_streams_are_bit_equal_to_one_stream(dims):
+    """The conditional and the unconditional pass of a step issued on two HIP streams (wan/utils/two_pass.py: what WanT2V.generate and
+    bench.py do on one rank) against the same passes back to back on one stream, a sampling loop of several steps with the fused CFG +
+    scheduler update in between: every latent bit-equal -- the kernels of one pass share no mutable state with those of the other, so
+    running beside each other must not change a bit (cf. tests/test_gpu_corun.py).  Second case: two blocks at the 1.3B width, 7800
+    tokens, the headline quant config (ViDiT on q / k / v)."""
+    from qdiff import config as qcfg
+    from qdiff.base.quant_layer import QuantizedLinear
+    from wan import calib
+    from wan.configs import seq_len_for
+    from wan.modules.model import WanModel
+    from wan.quant_wanx import QuantWanModel
+    from wan.utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
+    from wan.utils.fused_step import FusedStep
+    from wan.utils.two_pass import TwoPassStreams
+
+    dim, ffn, heads, layers, shape = dims
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    quant_config = qcfg.load(os.path.join(root, "wan2.1-quantization_amd", "quant_configs", "w8a8_all_linears.yaml"))
+    torch.manual_seed(0)
+    with torch.device(DEV):
+        fp = WanModel(dim=dim, ffn_dim=ffn, num_heads=heads, num_layers=layers, text_dim=64, freq_dim=64).eval()
+    g = torch.Generator(device=DEV).manual_seed(2)
+    torch.nn.init.xavier_uniform_(fp.head.head.weight, generator=g)
+    seq_len = seq_len_for(shape)
+    ctx = [torch.randn(24, 64, device=DEV, generator=g) * 0.1 for _ in range(2)]
+    lat0 = torch.randn(shape, device=DEV, generator=g)
+    model = QuantWanModel.from_float(fp, quant_config)
+    model.quant_layer_refactor()
+    hooks = calib.add_hooks(fp)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        fp([lat0], torch.tensor([900], device=DEV), [ctx[0]], seq_len)
+    data = calib.gather_and_save_activation(hooks)
+    gen = torch.Generator().manual_seed(0)
+    for name, mod in model.named_modules():
+        if isinstance(mod, QuantizedLinear) and (mod.uses_mask or mod.uses_rotation):
+            calib.init_rotation_and_channel_mask_(mod, name, data, gen)
+    model.set_init_done()
+    model.hardware_forward_refactor()
+
+    def loop(two):
+        sched = FlowUniPCMultistepScheduler(1000, shift=1.0)
+        sched.set_timesteps(6, device=DEV, shift=5.0)
+        fused = FusedStep(sched, 5.0, lat0)
+        lat, lats = lat0, []
+        for t in sched.timesteps:
+            cond, uncond = two(lambda c: model([lat], t.reshape(1), [c], seq_len)[0], lat, ctx)
+            lat = fused.step(cond, uncond, lat, t)
+            lats.append(lat.clone())
+        torch.cuda.synchronize()
+        return lats
+
+    one = loop(TwoPassStreams(DEV, enabled=False))
+    two = TwoPassStreams(DEV, enabled=True)
+    both = loop(two)
+    assert two.enabled and two.warm
+    for a, b in zip(one, both):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    # and again: the second loop's first step is already on two streams (the caches are filled)
+    for a, b in zip(one, loop(two)):
+        assert torch.equal(a, b)

@@ -17,6 +17,7 @@ from .configs import latent_shape, seq_len_for
 from .modules.model import WanModel
 from .utils.fm_solvers import FlowDPMSolverMultistepScheduler, FlowMatchScheduler
 from .utils.fused_step import FusedStep
+from .utils.two_pass import TwoPassStreams
 from .utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
 
 logger = logging.getLogger(__name__)
@@ -101,6 +102,9 @@ class WanT2V:
         plan = self.plan
         sp = plan.sp if plan is not None else None
         kw = {"sp": sp} if sp is not None and sp.size > 1 else {}
+        # one rank, kernel mode: the two passes of a step on two HIP streams (wan/utils/two_pass.py; WANQ_PASS_STREAMS=1: one stream)
+        two = TwoPassStreams(self.device, enabled=None if (latent.is_cuda and not kw and (plan is None or plan.cfg_degree == 1)
+                                                            and getattr(self.model, "hip_blocks", None) is not None) else False)
         with torch.no_grad(), torch.autocast("cuda", dtype=self.param_dtype):
             for i, t in enumerate(sched.timesteps):
                 ts = t.reshape(1)
@@ -108,8 +112,7 @@ class WanT2V:
                     mine = self.model([latent], ts, [context if plan.cfg_index == 0 else context_null], seq_len, **kw)[0]
                     cond, uncond = plan.gather_cfg(mine)
                 else:
-                    cond = self.model([latent], ts, [context], seq_len, **kw)[0]
-                    uncond = self.model([latent], ts, [context_null], seq_len, **kw)[0]
+                    cond, uncond = two(lambda c: self.model([latent], ts, [c], seq_len, **kw)[0], latent, [context, context_null])
                 if fused is not None:
                     latent = fused.step(cond.float(), uncond.float(), latent, t)
                 else:
