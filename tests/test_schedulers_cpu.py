@@ -182,3 +182,16 @@ def test_dpmpp_vs_reference_golden(n):
         x = s.step(torch.from_numpy(g["model_out"][i]), t, x)
         ref = g["x"][i + 1]
         assert float(np.abs(x.numpy() - ref).max()) <= 2e-5 * float(np.abs(ref).max()), (n, i)
+
+
+def test_two_pass_helper_is_sequential_without_a_gpu():
+    """wan/utils/two_pass.py on a CPU tensor: no streams exist, the two passes run back to back in order (the reference's order)."""
+    import torch
+
+    from wan.utils.two_pass import TwoPassStreams
+
+    two = TwoPassStreams("cpu")
+    assert not two.enabled and two.streams is None
+    seen = []
+    outs = two(lambda c: (seen.append(c), torch.full((2,), float(c)))[1], torch.zeros(2), [3, 5])
+    assert seen == [3, 5] and [o[0].item() for o in outs] == [3.0, 5.0]
