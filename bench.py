@@ -192,6 +192,9 @@ def main():
                     help="2 (default; one rank without cfg parallelism): the conditional and the unconditional pass of a step are issued on two "
                          "HIP streams (wan/utils/two_pass.py, what WanT2V.generate does), so that one pass's kernels fill the other's launch "
                          "boundaries: 1.033x, bit-equal results; 1: back to back on one stream, as the reference runs them")
+    ap.add_argument("--no-instrumented-repeat", dest="no_repeat", action="store_true",
+                    help="diagnostic (kernel traces of the timed steps themselves): skip the instrumented repeat of the K steps; the line then "
+                         "carries no roofline objects")
     ap.add_argument("--no-context-cache", dest="no_context_cache", action="store_true",
                     help="recompute cross_attn.k / cross_attn.v (+ RMSNorm) of the text context in every DiT pass, as round 2 did: they "
                          "do not depend on the timestep, and by default they are computed once per context tensor and kept "
@@ -388,10 +391,10 @@ def main():
     wanq_C.set_call_timer(htimer)  # the HBM-bound row-wise kernels of the step (an event pair around each launch)
     torch.cuda.synchronize()
     tp0 = time.perf_counter()
-    for i in range(total, total + args.steps):
+    for i in range(total, total + (0 if args.no_repeat else args.steps)):
         latent = step(latent, i)
     torch.cuda.synchronize()
-    dt_prof = time.perf_counter() - tp0
+    dt_prof = max(time.perf_counter() - tp0, 1e-9)
     qgemm.set_timer(None)
     wan_ops.set_attention_timer(None)
     wanq_C.set_call_timer(None)

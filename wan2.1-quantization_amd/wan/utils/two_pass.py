@@ -2,9 +2,10 @@
 
 The reference runs them back to back on one stream.  They are independent until the guidance combine, and every kernel of a pass is
 sized to fill the GPU, so issuing them on two streams does not make the GPU run two passes "in parallel": what it does is let one
-pass's next kernel start in the other's launch boundary (the end-of-kernel cache write-back, the dispatch latency of the next
-launch: ~10 us x ~1200 launches = ~3 % of the cfg-B step).  Measured: 427.5 -> 413.7 ms per step (1.033x), alternating runs
-on one box (profiles/r05_q_pass_streams_ab.txt); results bit-equal to the one-stream order (tests/test_gpu_step.py): every kernel
+pass's next kernel start on the CUs the other's kernel has already left -- the ramp-up of a launch, the drain of its last workgroups
+and half-empty last rounds (ffn.0's persistent GEMM: 17.5 tiles per workgroup) are where a one-stream step idles; between kernels it
+hardly does (1.4 ms of 425: profiles/r05_s_idle_between_kernels.txt).  Measured: 427.5 -> 413.7 ms per step (1.033x), 422.0 -> 415.6,
+438.7 -> 433.6 on three boxes, alternating runs (profiles/r05_q_*, r05_r_*, r05_zz_bench_line*.txt); results bit-equal to the one-stream order (tests/test_gpu_step.py): every kernel
 of the path is deterministic and none shares mutable state with a kernel of the other pass.
 
 Rules this helper keeps: the first step it sees runs on ONE stream (it fills what both passes later only read: the per-context
