@@ -188,10 +188,12 @@ def main():
     ap.add_argument("--graph", type=int, default=int(os.environ.get("WANQ_BENCH_GRAPH", "0")), choices=[0, 1],
                     help="1 (single GPU only): the two DiT passes of a step are replayed from a captured HIP graph "
                          "(wan/graph.py); 0 (default): every kernel is launched eagerly -- measured the same (DESIGN.md 5): the host runs ahead")
-    ap.add_argument("--pass-streams", dest="pass_streams", type=int, default=int(os.environ.get("WANQ_PASS_STREAMS", "2")), choices=[1, 2],
-                    help="2 (default; one rank without cfg parallelism): the conditional and the unconditional pass of a step are issued on two "
-                         "HIP streams (wan/utils/two_pass.py, what WanT2V.generate does), so that one pass's kernels fill the other's launch "
-                         "boundaries: 1.033x, bit-equal results; 1: back to back on one stream, as the reference runs them")
+    ap.add_argument("--pass-streams", dest="pass_streams", default=os.environ.get("WANQ_PASS_STREAMS", "auto"), choices=["auto", "1", "2"],
+                    help="one rank without cfg parallelism: the conditional and the unconditional pass of a step back to back on one stream, as "
+                         "the reference runs them (1), or on two HIP streams (2: wan/utils/two_pass.py; bit-equal results, one pass's kernels fill "
+                         "the other's launch boundaries -- faster by 0 - 3 %% at cfg-B depending on the box, slower at the 14B shapes).  auto "
+                         "(default, what WanT2V.generate does): three untimed evaluations before the warm-up steps -- one to fill the caches, one "
+                         "timed on one stream, one on two -- pick; the choice and its two timings are in config.launch")
     ap.add_argument("--no-instrumented-repeat", dest="no_repeat", action="store_true",
                     help="diagnostic (kernel traces of the timed steps themselves): skip the instrumented repeat of the K steps; the line then "
                          "carries no roofline objects")
@@ -332,13 +334,12 @@ def main():
     fused = FusedStep(sched, args.guide, latent0)  # CFG combine + UniPC update: one kernel per step
     graphed = None
     use_graph = [bool(args.graph) and world == 1]
-    two_was_on = args.pass_streams == 2 and world == 1 and not use_graph[0]
     if use_graph[0]:
         from wan.graph import GraphedPasses
         graphed = GraphedPasses(model, latent0, [ctx_c, ctx_u], seq_len)
 
     from wan.utils.two_pass import TwoPassStreams
-    two = TwoPassStreams(dev, enabled=args.pass_streams == 2 and plan.cfg_degree == 1 and world == 1)
+    two = TwoPassStreams(dev, enabled=plan.cfg_degree == 1 and world == 1 and not use_graph[0], mode=args.pass_streams)
 
     def step(latent, i):
         t = sched.timesteps[i:i + 1]
@@ -355,8 +356,10 @@ def main():
         return fused.step(cond, uncond, latent, sched.timesteps[i])
 
     latent = latent0
-    if two.enabled and args.warmup == 0:  # the helper's first call runs on one stream (it fills the caches both passes read): keep it untimed
-        two(lambda c: model([latent0], sched.timesteps[0:1], [c], seq_len, plan.sp)[0], latent0, [ctx_c, ctx_u])
+    # untimed, before the warm-up steps: the helper's first call (one stream: it fills the caches both passes read) and, in auto mode, the
+    # measurement that picks the order of the two passes -- the warm-up and the timed steps then run ONE schedule
+    two.tune(lambda c: model([latent0], sched.timesteps[0:1], [c], seq_len, plan.sp)[0], latent0, [ctx_c, ctx_u])
+    launch_desc = two.describe()
     for i in range(args.warmup):
         latent = step(latent, i)
     from wan import ops as wan_ops
@@ -415,7 +418,7 @@ def main():
                                                              "of_MB": round(len(sharded.blocks) * sharded.full_bytes / 1e6, 1),
                                                              "w4_unpack_scratch_MB": round(qgemm.w4_scratch_bytes(dev) / 1e6, 1)},
                    "launch": "hip graph replay of the two DiT passes + 1 fused CFG/scheduler kernel" if graphed is not None else
-                             ("eager launches, the two passes of a step on two HIP streams (wan/utils/two_pass.py)" if two_was_on else "eager launches")
+                             f"eager launches, the two passes of a step on {launch_desc}"
                              + " + 1 fused CFG/scheduler kernel",
                    "rccl_ranks": dist.get_world_size() if world > 1 else 1,
                    # Ulysses exchange of THIS rank inside the timed region (wan/distributed/parallel.py counts what it hands to

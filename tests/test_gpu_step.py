@@ -224,11 +224,19 @@ def test_two_pass_streams_are_bit_equal_to_one_stream(dims):
         return lats
 
     one = loop(TwoPassStreams(DEV, enabled=False))
-    two = TwoPassStreams(DEV, enabled=True)
+    two = TwoPassStreams(DEV, mode="2")
     both = loop(two)
-    assert two.enabled and two.warm
+    assert two.enabled and two.decided and two.calls == 6
     for a, b in zip(one, both):
         assert torch.isfinite(a).all() and torch.equal(a, b)
     # and again: the second loop's first step is already on two streams (the caches are filled)
     for a, b in zip(one, loop(two)):
         assert torch.equal(a, b)
+    # auto (the default): step 1 on one stream, step 2 timed on one, step 3 timed on two, then whichever was faster -- the latents do not
+    # depend on which
+    auto = TwoPassStreams(DEV, mode="auto")
+    assert not auto.decided
+    for a, b in zip(one, loop(auto)):
+        assert torch.equal(a, b)
+    assert auto.decided and auto.tuned is not None and min(auto.tuned) > 0 and auto.enabled == (auto.tuned[1] < 0.99 * auto.tuned[0])
+    assert ("two HIP streams" in auto.describe()) == auto.enabled

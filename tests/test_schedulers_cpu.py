@@ -195,3 +195,6 @@ def test_two_pass_helper_is_sequential_without_a_gpu():
     seen = []
     outs = two(lambda c: (seen.append(c), torch.full((2,), float(c)))[1], torch.zeros(2), [3, 5])
     assert seen == [3, 5] and [o[0].item() for o in outs] == [3.0, 5.0]
+    assert two.tune(lambda c: torch.zeros(1), torch.zeros(2), [3, 5]) is None and two.describe() == "one stream"
+    with pytest.raises(ValueError):
+        TwoPassStreams("cpu", mode="3")
