@@ -20,7 +20,8 @@ fi
 timeout -k 10 600 python bench.py > "$OUT/${TAG}_bench_line.txt" 2> "$OUT/${TAG}_bench.err" || { tail -5 "$OUT/${TAG}_bench.err"; exit 1; }
 cat "$OUT/${TAG}_bench_line.txt"
 # per-kernel statistics and the step breakdown are taken with the two passes of a step on ONE stream (--pass-streams 1): on two streams
-# (the default since round 5) kernels of the two passes share the GPU and a kernel's traced duration is no longer its own time
+# (what the default, auto, may pick: wan/utils/two_pass.py) kernels of the two passes share the GPU and a kernel's traced duration is no
+# longer its own time
 timeout -k 10 600 python bench.py --pass-streams 1 --no-cpu-baseline --no-quality > "$OUT/${TAG}_bench_line_one_stream.txt" 2>> "$OUT/${TAG}_bench.err" || { tail -5 "$OUT/${TAG}_bench.err"; exit 1; }
 MS=$(python3 -c "import json,sys; print(json.loads(open('$OUT/${TAG}_bench_line_one_stream.txt').read().strip().splitlines()[-1])['ms_per_step'])")
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_prof" -o "$TAG" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-quality --pass-streams 1 > "$OUT/${TAG}_prof_bench.log" 2>&1 || { tail -5 "$OUT/${TAG}_prof_bench.log"; exit 1; }
