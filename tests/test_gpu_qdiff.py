@@ -447,7 +447,7 @@ def test_surgery_and_param_dict_vs_reference_golden(golden):
 def test_smoothquant_linear_vs_reference_golden(golden):
     """SQQuantizedLinear (channel mask only) at in_features 1536 against the reference's own module (fixture a4_smoothquant_1536):
     mask, scaled + quantised weight bit for bit, forward output."""
-    from qdiff.base.quant_layer import SQQuantizedLinear
+    from qdiff.smooth_quant.sq_quant_layer import SQQuantizedLinear
 
     g = golden("a4_smoothquant_1536")
     n, out = 1536, 24
@@ -469,7 +469,7 @@ def test_quarot_linear_vs_reference_golden(golden):
     """QuarotQuantizedLinear (rotation only) at in_features 1536 against the reference's own module (fixture a4_quarot_1536):
     rotated + quantised weight (fp32 fast transform vs the reference's fp64 product: a code moves only at a .5 boundary),
     activation codes, forward output."""
-    from qdiff.base.quant_layer import QuarotQuantizedLinear
+    from qdiff.quarot.quarot_quant_layer import QuarotQuantizedLinear
 
     g = golden("a4_quarot_1536")
     n, out = 1536, 24

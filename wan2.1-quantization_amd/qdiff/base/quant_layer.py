@@ -1,4 +1,4 @@
-"""QuantizedLinear and its SmoothQuant / QuaRot / ViDiT variants in one place.
+"""QuantizedLinear: the base of the SmoothQuant / QuaRot / ViDiT variants (smooth_quant/, quarot/, viditq/), with everything they share.
 
 Interface of ViDiT-Q/quant_utils/qdiff/base/quant_layer.py:8-74 (+ smooth_quant/sq_quant_layer.py,
 quarot/quarot_quant_layer.py, viditq/viditq_quant_layer.py): ctor signature, attributes `fp_module`, `fp_weight`,
@@ -161,28 +161,3 @@ class QuantizedLinear(nn.Linear):
         """(w.double() @ R).float() evaluated as hadU(w * signs) in float64 (row i of R = sign_i * hadU(e_i))."""
         s = self.rotation_signs.to(w.device)
         return quarot_utils.matmul_hadU(w.double() * s).float()
-
-
-class SQQuantizedLinear(QuantizedLinear):
-    """SmoothQuant: channel mask only (smooth_quant/sq_quant_layer.py:6-68)."""
-    uses_mask = True
-
-    def __init__(self, in_features, out_features, bias, device, quant_config, fp_module):
-        super().__init__(in_features, out_features, bias, device, quant_config, fp_module)
-        self.alpha = quant_config.smooth_quant.alpha
-
-    def update_quantized_weight_scaled(self):
-        assert self.channel_mask is not None
-        self.w_quantizer.init_done = False
-        self._requantize(self.fp_module.weight.data.float() / self.channel_mask.reshape(1, -1))
-        self.w_quantizer.init_done = True
-
-
-class QuarotQuantizedLinear(QuantizedLinear):
-    """QuaRot: rotation only (quarot/quarot_quant_layer.py:7-69)."""
-    uses_rotation = True
-
-    def update_quantized_weight_rotated(self):
-        self.w_quantizer.init_done = False
-        self._requantize(self._rotate_weight(self.fp_module.weight.data.float()))
-        self.w_quantizer.init_done = True

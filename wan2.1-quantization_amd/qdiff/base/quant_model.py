@@ -8,8 +8,10 @@ import torch.nn as nn
 
 from ..utils import apply_func_to_submodules
 from .base_quantizer import BaseQuantizer
-from .quant_layer import QuantizedLinear, QuarotQuantizedLinear, SQQuantizedLinear
+from ..quarot.quarot_quant_layer import QuarotQuantizedLinear
+from ..smooth_quant.sq_quant_layer import SQQuantizedLinear
 from ..viditq.viditq_quant_layer import ViDiTQuantizedLinear
+from .quant_layer import QuantizedLinear
 
 logger = logging.getLogger(__name__)
 
