@@ -111,6 +111,51 @@ def test_wan_model_forward_vs_reference_model_py(gm):
     assert out.shape == (16, 3, 8, 6) and max(e0, e1, eo) < 2e-2
 
 
+@pytest.mark.gpu
+def test_fp_model_fused_glue_against_the_torch_expressions(gm, monkeypatch):
+    """The FP blocks on the GPU run LayerNorm + modulate, RMSNorm + RoPE and gate + residual as the library's fused kernels
+    (wan/modules/model.py::fused_fp); WANQ_FP_FUSED=0 evaluates the reference's torch expressions.  Same model, same inputs, both ways:
+    what the first block's Linears see in front of any 16-bit rounding (the LayerNorm + modulate outputs: the calibration hooks' view)
+    agrees to fp32 rounding; block outputs and the model output to the 16-bit roundings inside the attention."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "wan2.1-quantization_amd"))
+    from wan.modules.model import WanModel
+
+    torch.manual_seed(0)
+    with torch.device("cuda"):
+        model = WanModel(model_type="t2v", patch_size=(1, 2, 2), text_len=32, in_dim=16, dim=256, ffn_dim=512, freq_dim=64, text_dim=64,
+                         out_dim=16, num_heads=2, num_layers=2, eps=1e-6).eval()
+    seeded_parameters_(model)
+    x, ctx, t = (torch.from_numpy(gm[k]).cuda() for k in ("in_x", "in_ctx", "in_t"))
+
+    def run(flag):
+        monkeypatch.setenv("WANQ_FP_FUSED", flag)
+        seen, hooks = {}, []
+        for name in ("blocks.0.self_attn.q", "blocks.0.self_attn.o", "blocks.0.cross_attn.q", "blocks.0.ffn.0", "blocks.1.self_attn.q", "head.head"):
+            mod = model.get_submodule(name)
+            hooks.append(mod.register_forward_pre_hook(lambda m, a, name=name: seen.__setitem__(name, a[0].detach().float().clone())))
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):  # as the pipeline runs it (text2video.py:213)
+            out = model([x], t, [ctx], int(gm["seq_len"]))[0]
+        for h in hooks:
+            h.remove()
+        return out.float(), seen
+
+    o1, s1 = run("1")
+    o0, s0 = run("0")
+
+    def rel(a, b):
+        return float((a - b).norm() / b.norm())
+
+    assert s1["blocks.0.self_attn.q"].dtype == torch.float32 and s1["blocks.0.self_attn.q"].shape == s0["blocks.0.self_attn.q"].shape
+    assert rel(s1["blocks.0.self_attn.q"], s0["blocks.0.self_attn.q"]) < 2e-6        # LayerNorm + modulate (shift e0, scale e1)
+    tol = 1e-2                                                                         # behind the 16-bit Linears and attention operands
+    assert rel(s1["blocks.0.self_attn.o"][:, :36], s0["blocks.0.self_attn.o"][:, :36]) < tol
+    for name in ("blocks.0.cross_attn.q", "blocks.0.ffn.0", "blocks.1.self_attn.q", "head.head"):
+        assert rel(s1[name][:, :36], s0[name][:, :36]) < tol, name
+    assert rel(o1, o0) < tol
+    ref = torch.from_numpy(gm["out"]).cuda()
+    assert rel(o1, ref) < 2e-2 and rel(o0, ref) < 2e-2
+
+
 def seeded_vidit(name, n):
     """tests/golden/make_golden_model.py::seeded_vidit."""
     g = torch.Generator().manual_seed(zlib.crc32((name + ".vidit").encode()))

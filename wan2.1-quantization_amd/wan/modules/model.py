@@ -11,10 +11,34 @@ import os
 import torch
 import torch.nn as nn
 
+from viditq_extension import fused
+
 from .. import ops
 
 __all__ = ["WanModel", "WanAttentionBlock", "WanSelfAttention", "WanT2VCrossAttention", "WanRMSNorm", "WanLayerNorm",
            "sinusoidal_embedding_1d", "rope_params", "rope_apply"]
+
+
+def fused_fp(x):
+    """The FP blocks' row-wise glue on the GPU (LayerNorm + modulate, RMSNorm + rotary embedding, gate + residual) runs as the library's
+    fused kernels -- the ones kernel mode uses, fp32 arithmetic -- instead of eight to twelve torch launches each: the FP pass is what
+    fp_generate.py and the calibration passes of get_calib_data_wanx.py run (BASELINE config 3), and at the headline size 40 % of it was
+    that glue (profiles/r05_fp_*).  Results differ from the torch expressions by fp32 rounding order, and by the one 16-bit rounding
+    torch's RMSNorm makes between the normalisation and the weight under autocast (.type_as(x)).  WANQ_FP_FUSED=0, or a CPU tensor (the
+    golden-fixture tests of tests/test_model_golden.py): the torch expressions of the reference."""
+    return x.is_cuda and os.environ.get("WANQ_FP_FUSED", "1") != "0"
+
+
+_ROPE_TABLES = {}
+
+
+def _rope_table(freqs, grid, device):
+    key = (freqs.data_ptr(), tuple(grid), str(device))
+    if key not in _ROPE_TABLES:
+        if len(_ROPE_TABLES) > 8:
+            _ROPE_TABLES.clear()
+        _ROPE_TABLES[key] = ops.rope_table(freqs, grid, device)
+    return _ROPE_TABLES[key]
 
 
 def sinusoidal_embedding_1d(dim, position):
@@ -85,16 +109,31 @@ class WanSelfAttention(nn.Module):
         attention runs on H/P heads over the whole sequence, and the output comes back (usp_attn_forward,
         W/wan/distributed/xdit_context_parallel.py:149-192)."""
         b, s, n, d = x.shape[0], x.shape[1], self.num_heads, self.head_dim
-        q = self.norm_q(self.q(x)).view(b, s, n, d)
-        k = self.norm_k(self.k(x)).view(b, s, n, d)
-        v = self.v(x).view(b, s, n, d)
         par = sp is not None and sp.size > 1
+        fuse = fused_fp(x) and self.qk_norm
+        if fuse:  # RMSNorm + rotary embedding of q and k: one kernel each, in place on the projections
+            q, k, v = self.q(x), self.k(x), self.v(x)
+        else:
+            q = self.norm_q(self.q(x)).view(b, s, n, d)
+            k = self.norm_k(self.k(x)).view(b, s, n, d)
+            v = self.v(x).view(b, s, n, d)
         outs = []
         for i in range(b):
             off = sp.rank * s if par else 0
-            qi = rope_apply(q[i], grid_sizes[i], freqs, off).to(torch.bfloat16).flatten(1)
-            ki = rope_apply(k[i], grid_sizes[i], freqs, off).to(torch.bfloat16).flatten(1)
-            vi = v[i].to(torch.bfloat16).flatten(1)
+            if fuse:
+                tab = _rope_table(freqs, grid_sizes[i], x.device)[off:off + s]  # rows past the grid pass through (no table row)
+                qi, ki = q[i].contiguous(), k[i].contiguous()
+                if tab.shape[0]:
+                    ops.rmsnorm_rope_(qi, self.norm_q.weight.float(), tab, d, eps=self.norm_q.eps)
+                    ops.rmsnorm_rope_(ki, self.norm_k.weight.float(), tab, d, eps=self.norm_k.eps)
+                else:
+                    ops.rmsnorm_rope_(qi, self.norm_q.weight.float(), None, d, eps=self.norm_q.eps)
+                    ops.rmsnorm_rope_(ki, self.norm_k.weight.float(), None, d, eps=self.norm_k.eps)
+                qi, ki, vi = qi.to(torch.bfloat16), ki.to(torch.bfloat16), v[i].to(torch.bfloat16).contiguous()
+            else:
+                qi = rope_apply(q[i], grid_sizes[i], freqs, off).to(torch.bfloat16).flatten(1)
+                ki = rope_apply(k[i], grid_sizes[i], freqs, off).to(torch.bfloat16).flatten(1)
+                vi = v[i].to(torch.bfloat16).flatten(1)
             if par:
                 wq, wk, wv = (sp.scatter_heads(t_, async_op=True) for t_ in (qi, ki, vi))
                 oi = ops.attention(wq.wait(), wk.wait(), wv.wait(), n // sp.size, int(seq_lens[i]))
@@ -107,8 +146,14 @@ class WanSelfAttention(nn.Module):
 class WanT2VCrossAttention(WanSelfAttention):
     def forward(self, x, context, context_lens):
         b, n = x.shape[0], self.num_heads
-        q = self.norm_q(self.q(x))
-        k = self.norm_k(self.k(context))
+        if fused_fp(x) and self.qk_norm:
+            q, k = self.q(x).contiguous(), self.k(context).contiguous()
+            for i in range(b):
+                ops.rmsnorm_rope_(q[i], self.norm_q.weight.float(), None, self.head_dim, eps=self.norm_q.eps)
+                ops.rmsnorm_rope_(k[i], self.norm_k.weight.float(), None, self.head_dim, eps=self.norm_k.eps)
+        else:
+            q = self.norm_q(self.q(x))
+            k = self.norm_k(self.k(context))
         v = self.v(context)
         outs = [ops.attention(q[i].to(torch.bfloat16), k[i].to(torch.bfloat16), v[i].to(torch.bfloat16), n,
                               None if context_lens is None else int(context_lens[i])) for i in range(b)]
@@ -132,6 +177,8 @@ class WanAttentionBlock(nn.Module):
     def forward(self, x, e, seq_lens, grid_sizes, freqs, context, context_lens, sp=None):
         """x [B, L, C] fp32 residual stream (a token shard under Ulysses: everything but the self-attention is token-local),
         e [B, 6, C] fp32 (reference model.py:293-370)."""
+        if fused_fp(x):
+            return self._forward_fused(x, e, seq_lens, grid_sizes, freqs, context, context_lens, sp)
         with torch.autocast("cuda", enabled=False):
             e = (self.modulation.float() + e.float()).chunk(6, dim=1)
         y = self.self_attn(self.norm1(x).float() * (1 + e[1]) + e[0], seq_lens, grid_sizes, freqs, sp)
@@ -139,6 +186,32 @@ class WanAttentionBlock(nn.Module):
         x = x + self.cross_attn(self.norm3(x), context, context_lens).float()
         y = self.ffn(self.norm2(x).float() * (1 + e[4]) + e[3])
         return x + y.float() * e[5]
+
+    def _forward_fused(self, x, e, seq_lens, grid_sizes, freqs, context, context_lens, sp):
+        """The same block with LayerNorm + modulate and gate + residual as one kernel each (fp32 in, fp32 out: the Linears' forward
+        hooks of the calibration pass see fp32 inputs, as in the torch form)."""
+        B, L, C = x.shape
+        with torch.autocast("cuda", enabled=False):
+            e = (self.modulation.float() + e.float()).contiguous()  # [B, 6, C]
+        x2 = x.float().reshape(B * L, C)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+
+        def ln_mod(src, shift, scale):
+            h = torch.empty_like(src)
+            fused.layernorm_nobias_t2i_fuse(h, src, None, e[:, shift], e[:, scale], self.eps)
+            return h.view(B, L, C)
+
+        def add(src, y, gate):  # src + y * gate
+            y2 = y.reshape(B * L, C)
+            return fused.gate_residual_fuse(y2 if y2.is_contiguous() else y2.contiguous(), gate, src, out_dtype=torch.float32)
+
+        y = self.self_attn(ln_mod(x2, 0, 1), seq_lens, grid_sizes, freqs, sp)
+        x2 = add(x2, y, e[:, 2])
+        ones = e.new_ones(1, C).expand(B, C)
+        x2 = add(x2, self.cross_attn(self.norm3(x2.view(B, L, C)), context, context_lens), ones)
+        y = self.ffn(ln_mod(x2, 3, 4))
+        return add(x2, y, e[:, 5]).view(B, L, C)
 
 
 class Head(nn.Module):
