@@ -33,7 +33,8 @@ _ROPE_TABLES = {}
 
 
 def _rope_table(freqs, grid, device):
-    key = (freqs.data_ptr(), tuple(grid), str(device))
+    # WanModel.freqs is a fixed function of the head dimension (rope_params); two samples of the table guard a caller's own table
+    key = (freqs.shape[1], complex(freqs[1, 0]), complex(freqs[-1, -1]), tuple(grid), str(device))
     if key not in _ROPE_TABLES:
         if len(_ROPE_TABLES) > 8:
             _ROPE_TABLES.clear()
