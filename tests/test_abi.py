@@ -187,3 +187,29 @@ def test_wanq_lib_override_is_confined_to_the_package_lib_directory(tmp_path):
     r = subprocess.run([sys.executable, "-W", "always", "-c", code], env=dict(os.environ, WANQ_LIB=os.path.join(PKG, "lib", "libwanq_hip.so")),
                        capture_output=True, text=True)
     assert r.returncode == 0 and "WANQ_LIB overrides" in r.stderr
+
+
+def test_header_is_plain_c_and_a_c_program_links_against_the_library(lib, tmp_path):
+    """The boundary is a C ABI: include/wanq_hip.h compiles as pedantic C99 and as C++11, and a C program with no torch and no Python
+    in it links against lib/libwanq_hip.so, reads the ABI version and gets a refusal (code + message) for a null pointer -- no GPU
+    is touched by either call."""
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include <string.h>\n#include "wanq_hip.h"\n'
+                   "int main(void) {\n"
+                   "  int rc = wanq_quant_rows(NULL, WANQ_F32, NULL, NULL, NULL, WANQ_F32, 4, 64, 0, 0, NULL);\n"
+                   '  printf("%d %d %d\\n", wanq_abi_version(), rc, (int)strlen(wanq_last_error()));\n'
+                   "  return 0;\n}\n")
+    inc = os.path.join(ROOT, "include")
+    for cc, std in (("gcc", "-std=c99"), ("g++", "-std=c++11")):
+        r = subprocess.run([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", "-x", "c" if cc == "gcc" else "c++", str(src)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(LIB)
+    r = subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lwanq_hip", f"-Wl,-rpath,{libdir}",
+                        "-Wl,-rpath,/opt/rocm/lib", "-L", "/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    ver, rc, msg_len = map(int, r.stdout.split())
+    assert ver == lib.wanq_abi_version() and rc != 0 and msg_len > 0
