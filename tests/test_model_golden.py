@@ -416,3 +416,34 @@ def test_kernel_mode_blocks_teacher_forced_vs_reference_simulation_mode(gm):
         assert e < bars[tag] and c < shape_bar, (tag, i, e, c)
     for k, (e, c) in caught.items():
         assert e >= bars["a"] or c >= shape_bar, f"the test does not see the fault '{k}': {e:.2e} / {c:.3f}"
+
+
+def test_from_pretrained_and_from_float_copy_every_tensor_without_initial_draws(tmp_path):
+    """WanModel.from_pretrained (config.json + *.safetensors, the layout of a Wan2.1 checkpoint directory) and QuantWanModel.from_float
+    build their module tree without drawing initial values (`_skip_init`): every parameter must then come from the source -- equal
+    values, own storage -- and the RNG stream must not move (a skipped draw is the point)."""
+    import json
+
+    from safetensors.torch import save_file
+
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "wan2.1-quantization_amd"))
+    from wan.modules.model import WanModel
+    from wan.quant_wanx import QuantWanModel
+
+    torch.manual_seed(3)
+    src = WanModel(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64, freq_dim=64, text_len=32).eval()
+    with torch.no_grad():
+        src.head.head.weight.normal_()
+    json.dump({k: (list(v) if isinstance(v, tuple) else v) for k, v in src.config.items()}, open(tmp_path / "config.json", "w"))
+    save_file({k: v.contiguous() for k, v in src.state_dict().items()}, str(tmp_path / "model.safetensors"))
+    state = torch.get_rng_state()
+    a = WanModel.from_pretrained(str(tmp_path))
+    b = QuantWanModel.from_pretrained(str(tmp_path), None)
+    c = QuantWanModel.from_float(src, None)
+    assert torch.equal(torch.get_rng_state(), state)
+    want = src.state_dict()
+    for m in (a, b, c):
+        got = m.state_dict()
+        assert got.keys() == want.keys() and m.config == src.config and torch.equal(m.freqs, src.freqs)
+        for k in want:
+            assert torch.equal(got[k], want[k]) and got[k].data_ptr() != want[k].data_ptr(), k

@@ -4,6 +4,7 @@ apply unchanged), without diffusers / flash_attn: attention goes through wan.ops
 table is built once per grid, and the self-attention q path is the correct one (the reference's committed
 WanSelfAttention.forward drops norm_q and the head view -- SURVEY D1; semantics follow
 wan/distributed/xdit_context_parallel.py:162-170)."""
+import contextlib
 import json
 import math
 import os
@@ -234,7 +235,10 @@ class WanModel(nn.Module):
 
     def __init__(self, model_type="t2v", patch_size=(1, 2, 2), text_len=512, in_dim=16, dim=2048, ffn_dim=8192,
                  freq_dim=256, text_dim=4096, out_dim=16, num_heads=16, num_layers=32, window_size=(-1, -1),
-                 qk_norm=True, cross_attn_norm=True, eps=1e-6):
+                 qk_norm=True, cross_attn_norm=True, eps=1e-6, _skip_init=False, _device=None):
+        """_skip_init / _device: build the module tree WITHOUT drawing initial values, parameters left uninitialised on `_device` --
+        for callers that load a full state dict next (QuantWanModel.from_float / from_pretrained: drawing 1.4e9 -- or 1.4e10 --
+        uniform numbers on the host only to overwrite them was half of ptq_wanx.py's wall time)."""
         super().__init__()
         assert model_type == "t2v", "only the T2V backbone is in scope (SURVEY section 2.1)"
         self.config = dict(model_type=model_type, patch_size=tuple(patch_size), text_len=text_len, in_dim=in_dim, dim=dim,
@@ -243,18 +247,22 @@ class WanModel(nn.Module):
                            cross_attn_norm=cross_attn_norm, eps=eps)
         for k, v in self.config.items():
             setattr(self, k, v)
-        self.patch_embedding = nn.Conv3d(in_dim, dim, kernel_size=self.patch_size, stride=self.patch_size)
-        self.text_embedding = nn.Sequential(nn.Linear(text_dim, dim), nn.GELU(approximate="tanh"), nn.Linear(dim, dim))
-        self.time_embedding = nn.Sequential(nn.Linear(freq_dim, dim), nn.SiLU(), nn.Linear(dim, dim))
-        self.time_projection = nn.Sequential(nn.SiLU(), nn.Linear(dim, dim * 6))
-        self.blocks = nn.ModuleList([WanAttentionBlock("t2v_cross_attn", dim, ffn_dim, num_heads, window_size, qk_norm,
-                                                       cross_attn_norm, eps) for _ in range(num_layers)])
-        self.head = Head(dim, out_dim, self.patch_size, eps)
+        with torch.device("meta") if _skip_init else contextlib.nullcontext():
+            self.patch_embedding = nn.Conv3d(in_dim, dim, kernel_size=self.patch_size, stride=self.patch_size)
+            self.text_embedding = nn.Sequential(nn.Linear(text_dim, dim), nn.GELU(approximate="tanh"), nn.Linear(dim, dim))
+            self.time_embedding = nn.Sequential(nn.Linear(freq_dim, dim), nn.SiLU(), nn.Linear(dim, dim))
+            self.time_projection = nn.Sequential(nn.SiLU(), nn.Linear(dim, dim * 6))
+            self.blocks = nn.ModuleList([WanAttentionBlock("t2v_cross_attn", dim, ffn_dim, num_heads, window_size, qk_norm,
+                                                           cross_attn_norm, eps) for _ in range(num_layers)])
+            self.head = Head(dim, out_dim, self.patch_size, eps)
         d = dim // num_heads
         assert dim % num_heads == 0 and d % 2 == 0
         self.freqs = torch.cat([rope_params(1024, d - 4 * (d // 6)), rope_params(1024, 2 * (d // 6)),
                                 rope_params(1024, 2 * (d // 6))], dim=1)
-        self.init_weights()
+        if _skip_init:
+            self.to_empty(device=_device or "cpu")
+        else:
+            self.init_weights()
 
     def _patch_embed(self, u):
         """patch_embedding(u) for kernel == stride (model.py:580-582 of the reference calls the Conv3d): the convolution is a
@@ -334,7 +342,7 @@ class WanModel(nn.Module):
                 "num_heads", "num_layers", "window_size", "qk_norm", "cross_attn_norm", "eps")
         kw = {k: cfg[k] for k in keys if k in cfg}
         kw.update(overrides)
-        model = cls(**kw)
+        model = cls(_skip_init=True, **kw)  # every parameter comes from the checkpoint (strict load below)
         sd = {}
         for f in sorted(os.listdir(checkpoint_dir)):
             if f.endswith(".safetensors"):

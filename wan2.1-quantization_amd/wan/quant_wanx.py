@@ -33,15 +33,16 @@ class QuantWanModel(WanModel, QuantModel):
     @classmethod
     def from_pretrained(cls, checkpoint_dir, quant_config=None, **overrides):
         fp = WanModel.from_pretrained(checkpoint_dir, **overrides)
-        m = cls(quant_config, **fp.config)
-        m.load_state_dict(fp.state_dict())
-        return m
+        return cls.from_float(fp, quant_config)
 
     @classmethod
     def from_float(cls, fp_model, quant_config):
-        m = cls(quant_config, **fp_model.config)
-        m.load_state_dict(fp_model.state_dict())
-        return m.to(next(fp_model.parameters()).device)
+        """A quantisable copy of `fp_model` on its device: the module tree is built without drawing initial values (every parameter is
+        overwritten by the strict load that follows) and straight on that device (no host round trip of the weights)."""
+        dev = next(fp_model.parameters()).device
+        m = cls(quant_config, _skip_init=True, _device=dev, **fp_model.config)
+        m.load_state_dict(fp_model.state_dict(), strict=True)
+        return m
 
     def convert_quant(self, quant_config=None):
         if quant_config is not None:
