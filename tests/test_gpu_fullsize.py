@@ -760,3 +760,44 @@ def test_14b_block_WHOLE_output_vs_simulation_oracle_evaluated_on_the_gpu():
     assert err < 5e-3 and err < noise, (err, noise)  # below the flip floor, and below the quantisation effect it reproduces
     assert worst < 2e-3 and float(row_err.max()) < 1e-2, (worst, float(row_err.max()))
     assert shape < 0.05, shape
+
+
+def test_fp_block_fused_glue_full_size_against_the_torch_expressions(monkeypatch):
+    """One FP block at the headline size (32760 tokens, 1.3B width) under bf16 autocast, its row-wise glue on the fused kernels
+    (wan/modules/model.py::fused_fp, what fp_generate.py and the calibration passes run) against the reference's torch expressions
+    (WANQ_FP_FUSED=0): the LayerNorm + modulate output the q / k / v Linears (and the calibration hooks) see to fp32 rounding, the
+    block output to the 16-bit roundings of the Linears and of the attention operands."""
+    from wan.configs import seq_len_for
+    from wan.modules.model import WanAttentionBlock, rope_params
+
+    torch.manual_seed(0)
+    with torch.device(DEV):
+        blk = WanAttentionBlock("t2v_cross_attn", C, F, H, (-1, -1), True, True, 1e-6).eval()
+    g = torch.Generator(device=DEV).manual_seed(7)
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.dim() == 2:
+                torch.nn.init.xavier_uniform_(p, generator=g)
+    shape = (16, 21, 60, 104)
+    grid, seq_len = (21, 30, 52), seq_len_for(shape)
+    assert seq_len == L
+    x = torch.randn(1, L, C, device=DEV, generator=g)
+    e = torch.randn(1, 6, C, device=DEV, generator=g) * 0.1
+    ctx = torch.randn(1, 512, C, device=DEV, generator=g)
+    d = C // H
+    freqs = torch.cat([rope_params(1024, d - 4 * (d // 6)), rope_params(1024, 2 * (d // 6)), rope_params(1024, 2 * (d // 6))], dim=1)
+
+    def run(flag):
+        monkeypatch.setenv("WANQ_FP_FUSED", flag)
+        seen = {}
+        h = blk.self_attn.q.register_forward_pre_hook(lambda m, a: seen.__setitem__("q_in", a[0].detach().clone()))
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            out = blk(x, e, [L], [grid], freqs, ctx, None)
+        h.remove()
+        return out.float(), seen["q_in"]
+
+    o1, q1 = run("1")
+    o0, q0 = run("0")
+    assert q1.dtype == torch.float32 and q1.shape == q0.shape == (1, L, C)
+    assert float((q1 - q0).abs().max()) <= 2e-5 * float(q0.abs().max())
+    assert float((o1 - o0).norm() / o0.norm()) < 5e-3 and bool(torch.isfinite(o1).all())
