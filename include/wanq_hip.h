@@ -98,7 +98,8 @@ int wanq_gate_residual(const void* y, int y_dtype, const void* gate, int gate_dt
  * Any M >= 1 (ragged last tile handled in-kernel, no host padding: replaces pad_to_multiple_2d,
  * wan/quant_wanx_cuda.py:313-328); N % 8 == 0; K % 16 == 0.
  * Replaces qgemm.w8a8_of16_bias_weight_asym / _sym / w8a8_o32 / w8a8_of16_nobias_weight_sym_qserve
- *   (ViDiT-Q/kernels/csrc/qgemm/w8a8/w8a8_gemm_cuda.cu:624-838, ..._qserve.cu:527-611). */
+ *   (ViDiT-Q/kernels/csrc/qgemm/w8a8/w8a8_gemm_cuda.cu:624-838,
+ *    ViDiT-Q/kernels/csrc/qgemm/w8a8/w8a8_gemm_cuda_qserve.cu:527-611). */
 enum { WANQ_EPI_GELU = 1, WANQ_EPI_GATE_RES = 2 };
 int wanq_gemm_w8a8(const int8_t* a, const int8_t* w, void* out, int out_dtype, const void* sa,
                    const void* asum, int tok_dtype, const void* sw, const void* bias, int ch_dtype,
@@ -306,7 +307,7 @@ int wanq_unpack_w4(const uint8_t* packed, int8_t* q, int bias, int64_t rows, int
  *   acc[m,n] = sum_k a[m,k] * u[n,k];   y = acc*sa[m]*sw[n] (+ asum[m]*zp[n]*sw[n]) (+ bias[n]) ...   (same epilogue flags)
  * With zp = -zero this is y = acc*sW*sA - (sW*zW)*sumA (w4a8_per_channel_gemm_cuda_qserve.cu:580-587); signed qdiff codes q
  * stored with bias 8 use zp = zero_point - 8.  K % 32 == 0.
- * Replaces qgemm.w4a8_of16_nobias_weight_asym_qserve (ViDiT-Q/kernels/csrc/qgemm/w4a8/..._qserve.cu:304-656). */
+ * Replaces qgemm.w4a8_of16_nobias_weight_asym_qserve (ViDiT-Q/kernels/csrc/qgemm/w4a8/w4a8_per_channel_gemm_cuda_qserve.cu:304-656). */
 int wanq_gemm_w4a8(const int8_t* a, const uint8_t* w_packed, void* out, int out_dtype, const void* sa,
                    const void* asum, int tok_dtype, const void* sw, const void* bias, int ch_dtype,
                    const void* zp, int zp_dtype, const float* gate, const void* residual, int epi_flags,

@@ -38,3 +38,19 @@ def test_every_cited_path_exists():
                 continue
             missing += [(doc, p) for p in _expand(t) if not _exists(p)]
     assert not missing, missing
+
+
+def test_reference_citations_name_real_files_and_lines():
+    """Every `file:line` citation of the reference -- the header's "replaces ..." notes, the product's and the oracle's docstrings, the
+    documents -- names a file of the reference tree and lines inside it (tools/check_citations.py).  Needs /root/reference: skipped on a
+    box without it (the GPU box)."""
+    import subprocess
+    import sys
+
+    import pytest
+
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("the reference tree is not on this box")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_citations.py"), "--all"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert int(r.stdout.split()[0]) > 300

@@ -45,7 +45,7 @@ def get_sampling_sigmas(sampling_steps, shift):
 
 class FlowDPMSolverMultistepScheduler:
     """`--sample_solver dpm++`: DPM-Solver++ (2M, midpoint), data-prediction form, for flow-matching models
-    (ViDiT-Q/examples/Wan2.1/wan/utils/fm_solvers.py:69-860 -- diffusers' DPMSolverMultistepScheduler with the flow
+    (ViDiT-Q/examples/Wan2.1/wan/utils/fm_solvers.py:69-857 -- diffusers' DPMSolverMultistepScheduler with the flow
     parameterisation alpha = 1 - sigma; constructor defaults solver_order 2, algorithm_type "dpmsolver++", solver_type
     "midpoint", lower_order_final, final_sigmas_type "zero").  Host restatement like the UniPC one: float64 scalars, the update
     is linear in latent-sized tensors.  Restated lines: convert_model_output (flow_prediction) :341-395, first-order update
