@@ -192,8 +192,9 @@ def main():
                     help="one rank without cfg parallelism: the conditional and the unconditional pass of a step back to back on one stream, as "
                          "the reference runs them (1), or on two HIP streams (2: wan/utils/two_pass.py; bit-equal results, one pass's kernels fill "
                          "the other's launch boundaries -- faster by 0 - 3 %% at cfg-B depending on the box, slower at the 14B shapes).  auto "
-                         "(default, what WanT2V.generate does): three untimed evaluations before the warm-up steps -- one to fill the caches, one "
-                         "timed on one stream, one on two -- pick; the choice and its two timings are in config.launch")
+                         "(default, what WanT2V.generate does): five untimed evaluations before the warm-up steps -- one to fill the caches, then "
+                         "one stream / two streams / one / two, timed -- pick by the faster sample of each; the choice and its two timings are in "
+                         "config.launch")
     ap.add_argument("--no-instrumented-repeat", dest="no_repeat", action="store_true",
                     help="diagnostic (kernel traces of the timed steps themselves): skip the instrumented repeat of the K steps; the line then "
                          "carries no roofline objects")

@@ -232,8 +232,8 @@ def test_two_pass_streams_are_bit_equal_to_one_stream(dims):
     # and again: the second loop's first step is already on two streams (the caches are filled)
     for a, b in zip(one, loop(two)):
         assert torch.equal(a, b)
-    # auto (the default): step 1 on one stream, step 2 timed on one, step 3 timed on two, then whichever was faster -- the latents do not
-    # depend on which
+    # auto (the default): step 1 on one stream, steps 2 - 5 timed alternately on one stream and on two, then whichever was faster -- the
+    # latents do not depend on which
     auto = TwoPassStreams(DEV, mode="auto")
     assert not auto.decided
     for a, b in zip(one, loop(auto)):

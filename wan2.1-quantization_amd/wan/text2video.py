@@ -102,7 +102,7 @@ class WanT2V:
         plan = self.plan
         sp = plan.sp if plan is not None else None
         kw = {"sp": sp} if sp is not None and sp.size > 1 else {}
-        # one rank, kernel mode: the two passes of a step on one HIP stream or on two, whichever steps 2 and 3 of this loop measure faster
+        # one rank, kernel mode: the two passes of a step on one HIP stream or on two, whichever steps 2 - 5 of this loop measure faster
         # (wan/utils/two_pass.py: bit-equal latents either way; WANQ_PASS_STREAMS=1 / 2 fixes the order)
         two = TwoPassStreams(self.device, enabled=None if (latent.is_cuda and not kw and (plan is None or plan.cfg_degree == 1)
                                                             and getattr(self.model, "hip_blocks", None) is not None) else False)

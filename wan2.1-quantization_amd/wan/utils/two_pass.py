@@ -9,10 +9,11 @@ XCDs, so two heads' K / V (and two GEMMs' panels) share each L2 and the MALL.  W
 cfg-B (1.3B, L = 32760) 1.033x / 1.015x / 1.012x / 1.000x on four boxes, alternating runs; the 14B shapes on one GPU (L = 75600:
 twice the K / V per head) 0.96x (profiles/r05_q_*, r05_r_*, r05_u_*, r05_v_*).  So the order is CHOSEN BY MEASUREMENT at the start of
 a sampling loop (`mode="auto"`, the default): call 1 runs on one stream and fills what both passes later only read (per-context
-cross-attention k / v, rotary table, modulation table); call 2 is timed on one stream, call 3 on two (HIP events on the caller's
-stream; the only host synchronisation this helper ever makes, once, before call 4); two streams are kept when they were at least 1 %
-faster.  Results do not depend on the choice: latents are bit-equal either way (tests/test_gpu_step.py) -- every kernel of the path
-is deterministic and none shares mutable state with a kernel of the other pass.
+cross-attention k / v, rotary table, modulation table); calls 2 - 5 are timed alternately on one stream and on two (HIP events on
+the caller's stream; the only host synchronisation this helper ever makes, once, before call 6); two streams are kept when the
+faster of their two samples was at least 1 % below the faster of the one-stream samples.  Results do not depend on the choice:
+latents are bit-equal either way (tests/test_gpu_step.py) -- every kernel of the path is deterministic and none shares mutable state
+with a kernel of the other pass.
 
 Rules the two-stream order keeps: each pass runs wholly inside its stream's context, so its temporaries come from that stream's
 allocator pool; the latent is recorded on both side streams and the outputs on the caller's.  One rank without CFG parallelism only
@@ -69,26 +70,31 @@ class TwoPassStreams:
             return self._one(run_pass, contexts)          # (call 1: fills the caches both passes read)
         if self.decided:
             return self._two(run_pass, latent, contexts)
-        if self.calls == 2:
-            return self._timed(lambda: self._one(run_pass, contexts))
-        if self.calls == 3:
-            return self._timed(lambda: self._two(run_pass, latent, contexts))
-        self._ev[1][1].synchronize()                      # the one host wait: call 3 has finished
-        t1, t2 = (a.elapsed_time(b) for a, b in self._ev)
+        k = self.calls - 2                                # 0 .. 3: one, two, one, two
+        if k < 4:
+            return self._timed((lambda: self._one(run_pass, contexts)) if k % 2 == 0 else (lambda: self._two(run_pass, latent, contexts)))
+        self._decide()
+        return self._two(run_pass, latent, contexts) if self.enabled else self._one(run_pass, contexts)
+
+    def _decide(self):
+        self._ev[-1][1].synchronize()                     # the one host wait: the last timed call has finished
+        ms = [a.elapsed_time(b) for a, b in self._ev]
+        t1, t2 = min(ms[0::2]), min(ms[1::2])             # the faster of two samples each (a sample can only be slowed, not sped up)
         self.tuned, self._ev = (t1, t2), []
         self.decided = True
         self.enabled = t2 < 0.99 * t1
-        return self._two(run_pass, latent, contexts) if self.enabled else self._one(run_pass, contexts)
 
     def tune(self, run_pass, latent, contexts):
-        """Make the choice now, on three untimed evaluations of the two passes (bench.py: before its warm-up steps, so that the timed
+        """Make the choice now, on five untimed evaluations of the two passes (bench.py: before its warm-up steps, so that the timed
         region runs one schedule).  Returns (ms one stream, ms two streams) or None when there was nothing to choose."""
         if not self.enabled or self.decided:
             if self.calls == 0 and self.enabled:
                 self(run_pass, latent, contexts)          # still fill the caches on one stream
             return self.tuned
-        while not self.decided:
+        while len(self._ev) < 4 and not self.decided:
             self(run_pass, latent, contexts)
+        if not self.decided:
+            self._decide()
         return self.tuned
 
     def describe(self):
