@@ -663,6 +663,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef WANQ_ATTN_KASM
 #define WANQ_ATTN_KASM 4
 #endif
+// The wave index as a SCALAR (readfirstlane of threadIdx.x >> 6): hipcc cannot prove it uniform, and carried in a vector register it
+// made every LDS-DMA destination a v_readfirstlane + M0 write (8 per tile and DMA wave) and the dma_wave test an EXEC-mask branch; as a
+// scalar the issue of a tile is s_add / s_mov m0 / global_load_lds only.  Round 5: 4.806 -> 4.751 ms at 32760 x 32760 x 12 heads (1.012x),
+// cross-attention 1.026x, outputs bit-identical (profiles/r05_uw_attn_uniform_wave_ab.txt).  0 = the vector form, for A/B builds.
+#ifndef WANQ_ATTN_UNIFORM_WAVE
+#define WANQ_ATTN_UNIFORM_WAVE 1
+#endif
 #ifndef WANQ_ATTN_DMA_LATE
 #define WANQ_ATTN_DMA_LATE 0
 #endif
@@ -695,7 +702,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd16_kernel(const AttnParams
   constexpr int VOFF = QK8 ? AT_K8 : AT_TILE;  // byte offset of the V tile inside a stage
   typedef int v4i __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = WANQ_ATTN_UNIFORM_WAVE ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
   const int n16 = lane & 15, g4 = lane >> 4;
   int head = blockIdx.y, qblk = blockIdx.x;
   if (!SPLIT) {  // XCD-aware (head, query block) map, as in attn_fwd_kernel
