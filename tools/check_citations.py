@@ -12,6 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PREFIX = {"Q/": "ViDiT-Q/quant_utils/qdiff/", "K/": "ViDiT-Q/kernels/", "W/": "ViDiT-Q/examples/Wan2.1/"}
 CITE = re.compile(r"(?<![A-Za-z0-9_./\-])((?:[A-Za-z0-9_\-]+/)*[A-Za-z0-9_\-]+\.(?:py|cu|cuh|cpp|h|yaml|yml|sh)):(\d+)(?:-(\d+))?")
+MORE = re.compile(r",\s?(\d+)(?:-(\d+))?(?![\d.])")
 _INDEX = {}
 
 
@@ -44,19 +45,26 @@ def candidates(ref, path):
 def check_file(ref, src):
     bad, n = [], 0
     text = open(src, errors="replace").read()
+    cites = []
     for m in CITE.finditer(text):
-        path, a, b = m.group(1), int(m.group(2)), int(m.group(3) or m.group(2))
+        cites.append((m.group(0), m.group(1), int(m.group(2)), int(m.group(3) or m.group(2))))
+        for more in MORE.finditer(text, m.end()):      # "file.py:22-26, 69-857" / ":313-328,395-404": further ranges of the same file
+            if more.start() != (cites[-1][4] if len(cites[-1]) > 4 else m.end()):
+                break
+            cites[-1] = cites[-1][:4] + (more.end(),)
+            cites.append((m.group(1) + ":" + more.group(0).lstrip(", "), m.group(1), int(more.group(1)), int(more.group(2) or more.group(1)), more.end()))
+    for shown, path, a, b, *_ in cites:
         cands = candidates(ref, path)
         if cands is None:
             continue
         n += 1
         cands = [c for c in cands if os.path.isfile(c)]
         if not cands:
-            bad.append(f"{os.path.relpath(src, ROOT)}: {m.group(0)}: no such file in the reference")
+            bad.append(f"{os.path.relpath(src, ROOT)}: {shown}: no such file in the reference")
             continue
         lines = max(sum(1 for _ in open(c, errors="replace")) for c in cands)
         if not (1 <= a <= b <= lines):
-            bad.append(f"{os.path.relpath(src, ROOT)}: {m.group(0)}: the file has {lines} lines")
+            bad.append(f"{os.path.relpath(src, ROOT)}: {shown}: the file has {lines} lines")
     return n, bad
 
 
